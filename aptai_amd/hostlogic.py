@@ -1,0 +1,187 @@
+"""Host-side (integer / control) logic of the hot path.  No device work happens here.
+
+Every function cites the reference call site it mirrors.  "HF:" = the un-vendored
+``transformers/models/wav2vec2/modeling_wav2vec2.py`` (5.15.0 in the survey container).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+TV_NAMES = ("LA", "LP", "JA", "TTCL", "TTCD", "TMCL", "TMCD", "TBCL", "TBCD")   # models/aptai.py:67-70
+
+
+# ----------------------------------------------------------------------------- frame arithmetic
+def conv_out_length(n, kernel: int, stride: int):
+    """``floor((n - k) / s) + 1`` — HF:1004-1007 (torch.div(..., rounding_mode='floor') + 1)."""
+    if isinstance(n, torch.Tensor):
+        return torch.div(n - kernel, stride, rounding_mode="floor") + 1
+    if isinstance(n, np.ndarray):
+        return np.floor_divide(n - kernel, stride) + 1
+    return (int(n) - kernel) // stride + 1
+
+
+def feat_extract_output_lengths(n, conv_kernel: Sequence[int], conv_stride: Sequence[int]):
+    """HF:997-1016 ``_get_feat_extract_output_lengths`` (no adapter). Exact integer arithmetic."""
+    for k, s in zip(conv_kernel, conv_stride):
+        n = conv_out_length(n, k, s)
+    return n
+
+
+def conv_layer_lengths(n_samples: int, conv_kernel: Sequence[int], conv_stride: Sequence[int]) -> List[int]:
+    """Frame count after every conv layer (31999, 15999, ... 499 for 160000 samples)."""
+    out = []
+    n = int(n_samples)
+    for k, s in zip(conv_kernel, conv_stride):
+        n = (n - k) // s + 1
+        out.append(n)
+    return out
+
+
+def frame_attention_mask(n_frames: int, frame_lengths: torch.Tensor) -> torch.Tensor:
+    """(B, T) bool mask of valid frames — same result as HF:1018-1036's flip/cumsum construction."""
+    ar = torch.arange(n_frames, device=frame_lengths.device)
+    return ar[None, :] < frame_lengths[:, None]
+
+
+# ----------------------------------------------------------------------------- SpecAugment
+def compute_mask_indices(shape, mask_prob: float, mask_length: int,
+                         attention_mask: Optional[torch.Tensor] = None, min_masks: int = 0,
+                         rng=np.random) -> np.ndarray:
+    """SpecAugment span sampler, a restatement of HF:101-217 ``_compute_mask_indices``.
+
+    Consumes the numpy RNG in the same order as the reference (one ``rand(1)`` for the
+    probabilistic-rounding epsilon, then one ``choice`` per batch row) so that with the same
+    ``np.random.seed`` both produce the same mask.  Returns a (B, L) bool array.
+    """
+    batch_size, sequence_length = shape
+    if mask_length < 1:
+        raise ValueError("`mask_length` has to be bigger than 0.")
+    if mask_length > sequence_length:
+        raise ValueError(
+            f"`mask_length` has to be smaller than `sequence_length`, but got `mask_length`: {mask_length}"
+            f" and `sequence_length`: {sequence_length}`")
+
+    epsilon = rng.rand(1).item()
+
+    def num_spans(input_length):
+        n = int(mask_prob * input_length / mask_length + epsilon)
+        n = max(n, min_masks)
+        if n * mask_length > sequence_length:
+            n = sequence_length // mask_length
+        if input_length - (mask_length - 1) < n:
+            n = max(input_length - (mask_length - 1), 0)
+        return n
+
+    if attention_mask is not None:
+        input_lengths = [int(x) for x in attention_mask.detach().sum(-1).tolist()]
+    else:
+        input_lengths = [sequence_length] * batch_size
+
+    mask = np.zeros((batch_size, sequence_length), dtype=bool)
+    max_spans = num_spans(sequence_length)
+    if max_spans == 0:
+        return mask
+
+    rows = []
+    for input_length in input_lengths:
+        n = num_spans(input_length)
+        idx = rng.choice(np.arange(input_length - (mask_length - 1)), n, replace=False)
+        dummy = sequence_length - 1 if len(idx) == 0 else idx[0]
+        idx = np.concatenate([idx, np.ones(max_spans - n, dtype=np.int32) * dummy])
+        rows.append(idx)
+    starts = np.array(rows)
+    starts = np.broadcast_to(starts[:, :, None], (batch_size, max_spans, mask_length))
+    starts = starts.reshape(batch_size, max_spans * mask_length)
+    offsets = np.arange(mask_length)[None, None, :]
+    offsets = np.broadcast_to(offsets, (batch_size, max_spans, mask_length)).reshape(
+        batch_size, max_spans * mask_length)
+    idxs = starts + offsets
+    if idxs.max() > sequence_length - 1:
+        idxs[idxs > sequence_length - 1] = sequence_length - 1
+    np.put_along_axis(mask, idxs, 1, -1)
+    return mask
+
+
+# ----------------------------------------------------------------------------- optimiser schedule
+def get_lr_schedule(warmup_epochs: int, static_epochs: int, lr_decay: float) -> Callable[[int], float]:
+    """LambdaLR factor of train/train_aptai.py:372-386 — note the 10x during warm-up/static phases."""
+    def lambda_lr(epoch):
+        if epoch < warmup_epochs:
+            return 10. * (epoch + 1) / warmup_epochs
+        elif epoch < warmup_epochs + static_epochs:
+            return 10.
+        else:
+            return 10. * lr_decay ** (epoch - (warmup_epochs + static_epochs))
+    return lambda_lr
+
+
+# ----------------------------------------------------------------------------- collate (batch dict C0)
+def _pad(seqs, value):
+    return torch.nn.utils.rnn.pad_sequence(seqs, batch_first=True, padding_value=value)
+
+
+def collate_aptai(batch: List[dict], with_phoneme_labels: bool = False) -> Dict[str, torch.Tensor]:
+    """Batch dict of train/train_aptai.py:268-332 (+ ``phoneme_labels`` of train/train_force_aptai.py:271-275).
+
+    ``audio_inputs`` zero-padded f32, ``audio_lengths`` i64, ``phn_frames_49hz`` i64 padded with 0,
+    nine TV tracks f64 padded with -100.0.
+    """
+    out = {
+        "audio_inputs": _pad([torch.as_tensor(x["audio"]) for x in batch], 0.0),
+        "audio_lengths": torch.LongTensor([int(x["audio_len"]) for x in batch]),
+    }
+    if with_phoneme_labels:
+        out["phoneme_labels"] = _pad([torch.IntTensor(x["phoneme_label"]) for x in batch], -100)
+    out["phn_frames_49hz"] = _pad([torch.LongTensor(x["phn_frames_49hz"]) for x in batch], 0)
+    for name in TV_NAMES:
+        out[name] = _pad([torch.from_numpy(np.asarray(x["tvs_norm_49hz"][name])) for x in batch], -100.0)
+    return out
+
+
+def collate_pr(batch: List[dict]) -> Dict[str, torch.Tensor]:
+    """Batch dict of train/train_phoneme_recognizer.py:224-239 (labels padded with -100)."""
+    return {
+        "input_values": _pad([torch.as_tensor(x["audio"]) for x in batch], 0.0),
+        "input_lengths": torch.LongTensor([int(x["audio_len"]) for x in batch]),
+        "phoneme_labels": _pad([torch.IntTensor(x["phoneme_label"]) for x in batch], -100),
+    }
+
+
+def ctc_target_lengths(phoneme_labels: torch.Tensor) -> torch.Tensor:
+    """Count of labels >= 0 per row — the double Python loop of models/w2v2_pr.py:62-70, vectorised."""
+    return (phoneme_labels >= 0).sum(dim=-1).to(torch.long).cpu()
+
+
+# ----------------------------------------------------------------------------- low-pass taps (M1)
+def lowpass_taps(cutoff: float, sampling_rate: float) -> np.ndarray:
+    """51-tap Hann-windowed sinc of models/modules.py:27-44 (float64, unit DC gain)."""
+    fc = cutoff / sampling_rate
+    if fc > 0.5:
+        raise Exception('Cutoff frequency must be at least twice the sampling rate.')
+    b = 0.08
+    N = int(np.ceil(4 / b))
+    if not N % 2:
+        N += 1
+    n = np.arange(N)
+    h = np.sinc(fc * 2 * (n - (N - 1) / 2))
+    w = 0.5 * (1 - np.cos(n * 2 * np.pi / (N - 1)))
+    h = h * w
+    return h / np.sum(h)
+
+
+# ----------------------------------------------------------------------------- greedy CTC read-out
+def ctc_best_path(logits: np.ndarray, length: int, blank: int = 0) -> np.ndarray:
+    """Best-path decode: frame argmax -> collapse repeats -> drop blank.
+
+    Stands where the reference calls torchaudio's lexicon-free beam search
+    (models/w2v2_pr.py:143-159).  That decoder is not in the container: *parity unpinned*
+    (SURVEY.md §8c); with no LM the top beam is the best path up to beam pruning.
+    """
+    ids = np.asarray(logits)[:length].argmax(axis=-1)
+    keep = np.ones(len(ids), dtype=bool)
+    keep[1:] = ids[1:] != ids[:-1]
+    ids = ids[keep]
+    return ids[ids != blank].astype(np.int64)

@@ -1,0 +1,188 @@
+"""CPU: pin the oracle (oracle/*.py) against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  fp32 CPU vs fp32 CPU: tolerances are rounding-order only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import heads_ref, synth, w2v2_ref
+from aptai_amd.config import W2V2Config
+
+TV = ("LA", "LP", "JA", "TTCL", "TTCD", "TMCL", "TMCD", "TBCL", "TBCD")
+
+
+def _t(z, k):
+    return torch.from_numpy(np.asarray(z[k]))
+
+
+def _check_grads(z, named, prefix="", rtol=2e-3):
+    n_checked = 0
+    for key in z.files:
+        if key.startswith(prefix + "gnorm/"):
+            name = key[len(prefix + "gnorm/"):]
+            g = named[name].grad
+            assert g is not None, name
+            ref = float(z[key])
+            got = float(g.double().norm())
+            assert abs(got - ref) <= rtol * max(ref, 1e-6) + 1e-7, (name, got, ref)
+            n_checked += 1
+        if key.startswith(prefix + "gslice/"):
+            name = key[len(prefix + "gslice/"):]
+            flat = named[name].grad.float().flatten()
+            step = max(1, flat.numel() // 512)
+            got = flat[::step][:512].numpy()
+            ref = z[key]
+            scale = np.abs(ref).max() + 1e-12
+            assert np.abs(got - ref).max() <= 2e-3 * scale + 1e-7, name
+    assert n_checked > 0
+
+
+def test_ops_ctc():
+    z, _ = load_golden("ops_small")
+    logits = _t(z, "ctc/logits").requires_grad_(True)
+    lp = torch.log_softmax(logits, dim=-1)
+    tg, il, tl = _t(z, "ctc/targets"), z["ctc/input_lengths"], z["ctc/target_lengths"]
+    for red in ("mean", "sum", "none"):
+        for zi in (True, False):
+            got = heads_ref.ctc_loss_ref(lp, tg, il, tl, 0, red, zi).detach().numpy()
+            ref = z[f"ctc/loss_{red}_zi{int(zi)}"]
+            assert np.allclose(got, ref, rtol=1e-5, atol=1e-5, equal_nan=True), (red, zi, got, ref)
+    loss = heads_ref.ctc_loss_ref(lp, tg, il, tl, 0, "mean", True)
+    loss.backward()
+    # gradient w.r.t. the logits feeding log_softmax (torch's CTC backward folds the softmax Jacobian into
+    # the log_probs gradient, so only the end-to-end gradient is comparable)
+    g = torch.nan_to_num(logits.grad).numpy()
+    assert np.allclose(g, z["ctc/grad_logits_mean_zi1"], atol=2e-5)
+
+
+def test_ops_lengths_and_lowpass():
+    z, _ = load_golden("ops_small")
+    cfg = W2V2Config()
+    got = w2v2_ref.feat_extract_output_lengths(_t(z, "lens/in"), cfg).numpy()
+    assert (got == z["lens/out"]).all()
+    taps = heads_ref.lowpass_taps(10, 49)
+    assert np.array_equal(taps.numpy(), z["lowpass/taps"].reshape(-1))          # f64 bit-exact
+    for sfx in ("", "_short"):
+        out = heads_ref.lowpass_filter(_t(z, "lowpass/in" + sfx), taps).numpy()
+        assert np.allclose(out, z["lowpass/out" + sfx], atol=1e-6)
+
+
+def _pr_case(name):
+    z, meta = load_golden(name)
+    cfg = W2V2Config.from_any(meta["cfg"])
+    sd = synth.make_state_dict(synth.pr_param_shapes(cfg), meta["seed"])
+    for v in sd.values():
+        if v.dtype == torch.float32:
+            v.requires_grad_(True)
+    batch = {k: _t(z, "in/" + k) for k in ("input_values", "input_lengths", "phoneme_labels")}
+    # the committed inputs equal the synthetic-batch recipe
+    again = synth.synth_pr_batch(cfg, 2, meta["S"], seed=meta["batch_seed"],
+                                 lo=8 if meta["S"] < 32000 else 20, hi=12 if meta["S"] < 32000 else 55)
+    assert torch.equal(again["input_values"], batch["input_values"])
+    out = heads_ref.pr_forward(sd, cfg, training=True, **batch)
+    assert np.allclose(out["loss"].item(), z["train/loss"], rtol=2e-4)
+    assert np.abs(out["phoneme_logits"].detach().numpy() - z["train/phoneme_logits"]).max() < 2e-3
+    assert np.abs(out["log_probs"].detach().numpy() - z["train/log_probs"]).max() < 2e-3
+    out["loss"].backward()
+    _check_grads(z, sd)
+    return z, meta, cfg, sd, batch
+
+
+def test_pr_base_mini_and_specaugment():
+    z, meta, cfg, sd, batch = _pr_case("pr_base_mini_2x1s")
+    from aptai_amd import hostlogic
+    with torch.no_grad():
+        # SpecAugment: same numpy seed -> same spans -> same logits
+        T = z["train/phoneme_logits"].shape[1]
+        fl = w2v2_ref.feat_extract_output_lengths(batch["input_lengths"], cfg)
+        am = torch.arange(T)[None] < fl[:, None]
+        np.random.seed(int(z["specaug/np_seed"]))
+        m = hostlogic.compute_mask_indices((2, T), 0.05, 10, attention_mask=am, min_masks=2)
+        cfg2 = W2V2Config.from_any(dict(meta["cfg"], apply_spec_augment=True))
+        out = heads_ref.pr_forward(sd, cfg2, training=True, mask_time_indices=torch.from_numpy(m), **batch)
+        assert np.abs(out["phoneme_logits"].numpy()[:, ::3] - z["specaug/phoneme_logits_sub"]).max() < 2e-3
+        assert np.allclose(out["loss"].item(), z["specaug/loss"], rtol=2e-4)
+
+
+def test_mask_indices_match_hf():
+    from aptai_amd import hostlogic
+    z, _ = load_golden("ops_small")
+    for i in range(4):
+        shape = tuple(int(x) for x in z[f"mask/{i}/shape"])
+        lens = z[f"mask/{i}/lens"]
+        am = None if lens[0] < 0 else (torch.arange(shape[1])[None] < torch.from_numpy(lens)[:, None])
+        np.random.seed(int(z[f"mask/{i}/seed"]))
+        m = hostlogic.compute_mask_indices(shape, 0.05, 10, attention_mask=am, min_masks=2)
+        assert np.array_equal(m, z[f"mask/{i}/out"])
+
+
+def test_pr_base_config1():
+    """BASELINE config 1 (Wav2Vec2_PR, wav2vec2-base, 2 x 4 s) — the reference's CPU-runnable case."""
+    _pr_case("pr_base_2x4s")
+
+
+def test_aptai_large():
+    z, meta = load_golden("aptai_large_2x1s")
+    cfg = W2V2Config.from_any(meta["cfg"])
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), meta["seed"])
+    for k, v in sd.items():
+        if v.dtype == torch.float32 and "feature_extractor" not in k:
+            v.requires_grad_(True)
+    audio, lens, phn = _t(z, "in/audio_inputs"), _t(z, "in/audio_lengths"), _t(z, "in/phn_frames_49hz")
+    tvs = [_t(z, "in/" + n) for n in TV]
+    out = heads_ref.aptai_forward(sd, cfg, audio, lens, phn, tvs, training=True, tv_drop=0.0, phn_drop=0.0)
+    for k in ("loss", "mse_loss", "ce_loss"):
+        assert np.allclose(out[k].item(), z["train/" + k], rtol=3e-4), k
+    assert np.abs(out["tvs_pred"].detach().numpy() - z["train/tvs_pred"]).max() < 2e-3
+    for i in (0, 1, 12, 24):
+        h = out["hidden_states"][i].detach().numpy()[:, ::4, ::16]
+        ref = z[f"train/hidden_{i}_sub"]
+        assert np.abs(h - ref).max() < 2e-3 * max(1.0, np.abs(ref).max()), i
+    # argmax indices: identical wherever the reference's top-2 margin is not a float tie
+    assert (out["phn_fc_pred"].numpy() == z["train/phn_fc_pred"]).mean() > 0.999
+    out["loss"].backward()
+    _check_grads(z, sd)
+    assert not z["frozen_has_grad"].any()
+
+
+def test_force_aptai():
+    z, meta = load_golden("force_aptai_1x2s")
+    pr_cfg = W2V2Config.from_any(meta["pr_cfg"])
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, meta["vocab_len"]), meta["seed"])
+    sd["w2v2_pr.pr_head.bias"][0] += meta["blank_bias"]
+    for k, v in sd.items():
+        if v.dtype == torch.float32 and not k.startswith("w2v2_pr.") and k != "pe_phn.pe":
+            v.requires_grad_(True)
+    audio, lens = _t(z, "b1/in/audio_inputs"), _t(z, "b1/in/audio_lengths")
+    tvs = [_t(z, "b1/in/" + n) for n in TV]
+    out = heads_ref.force_aptai_forward(sd, pr_cfg, audio, lens, tvs,
+                                        phn_pred_list=[z["b1/pred_ctc_phn_seq"]], training=False)
+    # with drop=0 training==eval for these heads; rnn drop handled by p=0 in the fixture
+    for k in ("loss", "tv_loss", "align_loss"):
+        assert np.allclose(out[k].item(), z["b1/" + k], rtol=3e-4), (k, out[k].item(), z["b1/" + k])
+    assert np.abs(out["tvs_pred"].detach().numpy() - z["b1/tvs_pred"]).max() < 1e-3
+    assert out["pred_frame_phns"][0] == z["b1/pred_frame_phns"].tolist()          # bit-exact alignment
+    # greedy stand-in reproduces the stored decode (same definition on both sides: unpinned step)
+    out2 = heads_ref.force_aptai_forward(sd, pr_cfg, audio, lens, tvs, training=False)
+    assert np.array_equal(out2["pred_ctc_phn_seq"][0], z["b1/pred_ctc_phn_seq"])
+    out["loss"].backward()
+    _check_grads(z, sd, prefix="b1/", rtol=5e-3)
+    # ---- B=2 sub-module vectors
+    frame, ids = _t(z, "b2/frame"), _t(z, "b2/phn_ids")
+    mask = (ids != 0).to(torch.int)
+    with torch.no_grad():
+        emb = torch.nn.functional.embedding(ids, sd["phn_emb_layer.weight"], padding_idx=0)
+        emb = (emb.permute(1, 0, 2) + sd["pe_phn.pe"][:emb.size(1)]).permute(1, 0, 2)
+        assert np.abs(emb.numpy() - z["b2/phn_embs"]).max() < 1e-6
+        att_out, energy = heads_ref.cross_attention(sd, frame, emb, mask)
+        assert np.abs(att_out.numpy() - z["b2/att_out"]).max() < 1e-4
+        assert np.abs(energy.numpy() - z["b2/energy"]).max() < 1e-3
+        att = torch.log_softmax(energy + ((1 - mask) * -1000.0).unsqueeze(1).repeat(1, energy.size(1), 1), -1)
+        assert np.array_equal(torch.max(att, axis=2)[1].numpy(), z["b2/align_idx"])
+        fs = heads_ref.forward_sum_loss(att.unsqueeze(1), z["b2/text_lens"], z["b2/mel_lens"])
+        assert np.allclose(fs.item(), z["b2/fs_loss"], rtol=1e-4)
+        rnn_out, lstm_out = heads_ref.rnn_forward(sd, att_out, z["b2/mel_lens"].tolist())
+        assert np.abs(lstm_out.numpy() - z["b2/lstm_out"]).max() < 1e-4
+        assert np.abs(rnn_out.numpy() - z["b2/rnn_out"]).max() < 1e-4
+        tv = heads_ref.lowpass_filter(rnn_out, sd["tv_lowpass.lowpass.weight"].view(-1))
+        assert np.abs(tv.numpy() - z["b2/tvs"]).max() < 1e-5
