@@ -1,0 +1,100 @@
+// Shared device/host helpers for the aptai_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/aptai_hip.h"
+
+typedef uint16_t bf16_t;   // raw bfloat16 storage
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(8))) short short8v;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---------------------------------------------------------------------------------- error plumbing
+void aptai_set_error(const char* fmt, ...);
+#define APTAI_FAIL(code, ...)            \
+    do {                                 \
+        aptai_set_error(__VA_ARGS__);    \
+        return (code);                   \
+    } while (0)
+#define APTAI_REQUIRE(cond, ...)                                   \
+    do {                                                           \
+        if (!(cond)) APTAI_FAIL(APTAI_ERR_INVALID, __VA_ARGS__);   \
+    } while (0)
+#define APTAI_CHECK_LAUNCH(name)                                                          \
+    do {                                                                                  \
+        hipError_t e__ = hipGetLastError();                                               \
+        if (e__ != hipSuccess) APTAI_FAIL(APTAI_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------- bf16 <-> f32
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved)
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float lo_bf(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+
+// ---------------------------------------------------------------------------------- wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------- math
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---------------------------------------------------------------------------------- counter RNG (dropout)
+// One 32-bit hash per PAIR of elements (16 bits each): keep iff half >= thr16.  Forward and backward
+// regenerate the same mask from (seed, logical element index), whatever their thread mapping.
+__device__ __forceinline__ uint32_t rng_hash(uint32_t idx, uint32_t s0, uint32_t s1) {
+    uint32_t x = idx * 0x9E3779B1u + s0;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16; x += s1;
+    x ^= x >> 15; x *= 0x2c1b3c6du;
+    x ^= x >> 12;
+    return x;
+}
+// element index e (64-bit logical index folded to 32 bits by the caller when rows*cols < 2^32)
+__device__ __forceinline__ bool drop_keep(uint64_t e, uint32_t s0, uint32_t s1, uint32_t thr16) {
+    const uint32_t h = rng_hash((uint32_t)(e >> 1) ^ (uint32_t)(e >> 33) * 0x85ebca6bu, s0, s1);
+    const uint32_t half = (e & 1) ? (h >> 16) : (h & 0xffffu);
+    return half >= thr16;
+}
+static inline uint32_t drop_thr16(float p) {
+    if (p <= 0.f) return 0;
+    long t = (long)(p * 65536.0 + 0.5);
+    if (t > 65535) t = 65535;
+    return (uint32_t)t;
+}
+static inline float drop_scale(uint32_t thr16) { return thr16 ? 65536.0f / (65536.0f - (float)thr16) : 1.0f; }
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,308 @@
+// bf16 MFMA GEMM family for the wav2vec2 hot path (gfx950).
+//
+//   C[M,N] = rowop[M,K] . colop[N,K]^T     (fp32 accumulate on v_mfma_f32_16x16x32_bf16)
+//
+// Each operand is either K-contiguous in memory ([rows][K], "KC") or K-major ([K][rows], "KM"):
+//   NT  A=KC  B=KC : Linear forward  Y = X W^T            (HF nn.Linear call sites),
+//                    strided-row implicit GEMM for conv L1..L6 (K4: lda = stride*C < K = k*C)
+//   NN  A=KC  B=KM : dgrad          dX = dY W
+//   TN  A=KM  B=KM : wgrad          dW = dY^T X           (fp32 out, optional split-K slabs)
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), wave tile 64x64 = 4x4 MFMA tiles.  Tiles are staged
+// global->LDS by LDS-DMA (global_load_lds_dwordx4, 16 B/lane) into two stages; the XOR swizzle sits on the
+// per-lane SOURCE address and on the LDS read (LDS-DMA writes are lane-linear).  KC fragments are read with
+// ds_read_b128, KM fragments with ds_read_b64_tr_b16 (hardware transpose).  MFMA operands are swapped
+// (D = colfrag x rowfrag) so each lane ends up with 4 consecutive output columns -> 8/16-byte stores.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NTHREADS = 256;
+constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;   // 32 KiB
+constexpr int OPER_BYTES = BM * BK * 2;                // 16 KiB per operand tile
+
+struct GemmArgs {
+    const bf16_t* A; long lda;
+    const bf16_t* B; long ldb;
+    void* C; long ldc;
+    int M, N, K;
+    const float* bias;
+    const bf16_t* residual; long ldr;
+    bf16_t* out_pre;            // pre-activation copy (same ld as C)
+    const bf16_t* aux; long ldaux;
+    int flags;
+    uint32_t seed0, seed1, thr16;
+    float dscale;
+    float alpha;
+    int ktiles_per_split;
+    long slab_stride;           // elements between split-K slabs (fp32 out only)
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int km_swz(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
+
+// ---- global -> LDS staging of one operand tile (1024 x 16-B chunks, 4 per thread)
+template <bool KM>
+__device__ __forceinline__ void stage_operand(const bf16_t* __restrict__ base, long ld, int row0, int rows_total,
+                                              int k0, char* lds_tile, int tid, int wave_base_tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int cid = it * NTHREADS + tid;
+        const bf16_t* src;
+        if (!KM) {
+            const int row = cid >> 3, pc = cid & 7;
+            int grow = row0 + row;
+            grow = grow < rows_total ? grow : rows_total - 1;
+            src = base + (long)grow * ld + k0 + ((pc ^ (row & 7)) << 3);
+        } else {
+            const int krow = cid >> 4, pc = cid & 15;
+            int col = row0 + ((pc ^ km_swz(krow)) << 3);
+            col = col <= rows_total - 8 ? col : rows_total - 8;
+            src = base + (long)(k0 + krow) * ld + col;
+        }
+        char* dst = lds_tile + (it * NTHREADS + wave_base_tid) * 16;   // wave-uniform; HW adds lane*16
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst), 16, 0, 0);
+    }
+}
+
+// ---- fragment reads (16 rows x 32 k) for MFMA 16x16x32
+template <bool KM>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row_base, int ks, int lane) {
+    if (!KM) {
+        const int row = row_base + (lane & 15);
+        const int q = ks * 4 + (lane >> 4);
+        return *(const bf16x8*)(lds_tile + row * 128 + ((q ^ (row & 7)) << 4));
+    } else {
+        const int g = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3;
+        const int ch = (row_base >> 3) + (p >> 1);
+        const int sub = (p & 1) << 3;
+        const int k_lo = ks * 32 + g * 8 + qq;
+        const int k_hi = k_lo + 4;
+        const char* a0 = lds_tile + k_lo * 256 + ((ch ^ km_swz(k_lo)) << 4) + sub;
+        const char* a1 = lds_tile + k_hi * 256 + ((ch ^ km_swz(k_hi)) << 4) + sub;
+        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)a0);
+        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)a1);
+        short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, r);
+    }
+}
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int split = blockIdx.z;
+    const int total_kt = g.K / BK;
+    const int kt_begin = split * g.ktiles_per_split;
+    int kt_end = kt_begin + g.ktiles_per_split;
+    kt_end = kt_end < total_kt ? kt_end : total_kt;
+    const int nk = kt_end - kt_begin;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wave_base_tid = wave * 64;
+    if (nk > 0) {
+        stage_operand<A_KM>(g.A, g.lda, m0, g.M, kt_begin * BK, smem, tid, wave_base_tid);
+        stage_operand<B_KM>(g.B, g.ldb, n0, g.N, kt_begin * BK, smem + OPER_BYTES, tid, wave_base_tid);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            char* nxt = smem + (cur ^ 1) * STAGE_BYTES;
+            stage_operand<A_KM>(g.A, g.lda, m0, g.M, (kt_begin + kt + 1) * BK, nxt, tid, wave_base_tid);
+            stage_operand<B_KM>(g.B, g.ldb, n0, g.N, (kt_begin + kt + 1) * BK, nxt + OPER_BYTES, tid, wave_base_tid);
+        }
+        const char* sa = smem + cur * STAGE_BYTES;
+        const char* sb = sa + OPER_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = read_frag<A_KM>(sa, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<B_KM>(sb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // acc[i][j][r]: m = m0 + wm*64 + i*16 + (lane&15);  n = n0 + wn*64 + j*16 + (lane>>4)*4 + r
+    const int flags = g.flags;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= g.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (OUT_F32) {
+                float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
+                if (flags & APTAI_EPI_ALPHA) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
+                }
+                *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+            } else {
+                if (flags & APTAI_EPI_ALPHA) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
+                }
+                if (flags & APTAI_EPI_BIAS) {
+                    const f32x4 b = *(const f32x4*)(g.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += b[r];
+                }
+                if (g.out_pre) {
+                    u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                    *(u32x2*)(g.out_pre + (long)m * g.ldc + n) = o;
+                }
+                if (flags & APTAI_EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+                if (flags & APTAI_EPI_DROPOUT) {
+                    const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = drop_keep(e + r, g.seed0, g.seed1, g.thr16) ? v[r] * g.dscale : 0.f;
+                }
+                if (flags & APTAI_EPI_DGELU) {
+                    const u32x2 a = *(const u32x2*)(g.aux + (long)m * g.ldaux + n);
+                    v[0] *= gelu_erf_grad(lo_bf(a[0])); v[1] *= gelu_erf_grad(hi_bf(a[0]));
+                    v[2] *= gelu_erf_grad(lo_bf(a[1])); v[3] *= gelu_erf_grad(hi_bf(a[1]));
+                }
+                if (flags & APTAI_EPI_RESIDUAL) {
+                    const u32x2 a = *(const u32x2*)(g.residual + (long)m * g.ldr + n);
+                    v[0] += lo_bf(a[0]); v[1] += hi_bf(a[0]); v[2] += lo_bf(a[1]); v[3] += hi_bf(a[1]);
+                }
+                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                *(u32x2*)((bf16_t*)g.C + (long)m * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n4, long slab_stride4,
+                                     int nsplit, int accumulate) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 s = accumulate ? ((const f32x4*)out)[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nsplit; ++k) s += ((const f32x4*)slabs)[(long)k * slab_stride4 + i];
+        ((f32x4*)out)[i] = s;
+    }
+}
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+int launch_gemm(const GemmArgs& g, int nsplit, hipStream_t stream) {
+    auto kern = gemm_kernel<A_KM, B_KM, OUT_F32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        attr_set = true;
+    }
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nsplit);
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), 2 * STAGE_BYTES, stream, g);
+    APTAI_CHECK_LAUNCH("gemm_kernel");
+    return APTAI_OK;
+}
+
+}  // namespace
+
+extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APTAI_REQUIRE(d != nullptr, "aptai_gemm_bf16: null descriptor");
+    APTAI_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "aptai_gemm_bf16: empty problem M=%ld N=%ld K=%ld", (long)d->M,
+                  (long)d->N, (long)d->K);
+    APTAI_REQUIRE(d->K % BK == 0, "aptai_gemm_bf16: K=%ld must be a multiple of %d", (long)d->K, BK);
+    APTAI_REQUIRE(d->N % 8 == 0, "aptai_gemm_bf16: N=%ld must be a multiple of 8", (long)d->N);
+    APTAI_REQUIRE(d->A && d->B && d->C, "aptai_gemm_bf16: null operand");
+    APTAI_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 4 == 0, "aptai_gemm_bf16: leading dims must keep 16-B alignment");
+    APTAI_REQUIRE(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0) && ((uintptr_t)d->C % 16 == 0),
+                  "aptai_gemm_bf16: operands must be 16-byte aligned");
+    if (d->a_kmajor) APTAI_REQUIRE(d->M % 8 == 0 && d->M >= 8, "aptai_gemm_bf16: K-major A needs M %% 8 == 0");
+    if (d->b_kmajor) APTAI_REQUIRE(d->N >= 8, "aptai_gemm_bf16: K-major B needs N >= 8");
+    if (d->flags & APTAI_EPI_BIAS) APTAI_REQUIRE(d->bias != nullptr, "aptai_gemm_bf16: EPI_BIAS without bias");
+    if (d->flags & APTAI_EPI_RESIDUAL) APTAI_REQUIRE(d->residual != nullptr, "aptai_gemm_bf16: EPI_RESIDUAL without residual");
+    if (d->flags & APTAI_EPI_DGELU) APTAI_REQUIRE(d->aux != nullptr, "aptai_gemm_bf16: EPI_DGELU without aux");
+
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t*)d->A; g.lda = d->lda;
+    g.B = (const bf16_t*)d->B; g.ldb = d->ldb;
+    g.C = d->C; g.ldc = d->ldc;
+    g.M = (int)d->M; g.N = (int)d->N; g.K = (int)d->K;
+    g.bias = d->bias;
+    g.residual = (const bf16_t*)d->residual; g.ldr = d->ldr;
+    g.out_pre = (bf16_t*)d->out_pre;
+    g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux;
+    g.flags = d->flags;
+    g.seed0 = (uint32_t)d->seed; g.seed1 = (uint32_t)(d->seed >> 32);
+    g.thr16 = drop_thr16(d->dropout_p);
+    g.dscale = drop_scale(g.thr16);
+    if (g.thr16 == 0) g.flags &= ~APTAI_EPI_DROPOUT;
+    g.alpha = d->alpha;
+    g.tiles_m = (int)ceil_div(d->M, BM);
+    g.tiles_n = (int)ceil_div(d->N, BN);
+    const int total_kt = g.K / BK;
+    int nsplit = d->split_k > 0 ? d->split_k : 1;
+    if (nsplit > total_kt) nsplit = total_kt;
+    g.ktiles_per_split = (int)ceil_div(total_kt, nsplit);
+    nsplit = (int)ceil_div(total_kt, g.ktiles_per_split);
+
+    const bool f32 = d->out_f32 != 0;
+    if (!f32) APTAI_REQUIRE(nsplit == 1, "aptai_gemm_bf16: split-K needs fp32 output");
+    float* final_out = (float*)d->C;
+    if (f32 && (nsplit > 1 || d->accumulate)) {
+        APTAI_REQUIRE(d->workspace != nullptr, "aptai_gemm_bf16: split-K / accumulate needs a workspace");
+        APTAI_REQUIRE(d->ldc == d->N, "aptai_gemm_bf16: split-K output must be dense (ldc == N)");
+        APTAI_REQUIRE((size_t)d->workspace_bytes >= (size_t)nsplit * d->M * d->N * 4, "aptai_gemm_bf16: workspace too small");
+        g.C = d->workspace;
+        g.slab_stride = (long)d->M * d->N;
+    }
+    int rc;
+    if (!d->a_kmajor && !d->b_kmajor) rc = f32 ? launch_gemm<false, false, true>(g, nsplit, stream) : launch_gemm<false, false, false>(g, nsplit, stream);
+    else if (!d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm<false, true, true>(g, nsplit, stream) : launch_gemm<false, true, false>(g, nsplit, stream);
+    else if (d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm<true, true, true>(g, nsplit, stream) : launch_gemm<true, true, false>(g, nsplit, stream);
+    else APTAI_FAIL(APTAI_ERR_INVALID, "aptai_gemm_bf16: A K-major with B K-contiguous is not built");
+    if (rc != APTAI_OK) return rc;
+    if (f32 && (nsplit > 1 || d->accumulate)) {
+        const long n4 = (long)d->M * d->N / 4;
+        int blocks = (int)(n4 / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)d->workspace, final_out,
+                           n4, g.slab_stride / 4, nsplit, d->accumulate ? 1 : 0);
+        APTAI_CHECK_LAUNCH("splitk_reduce_kernel");
+    }
+    return APTAI_OK;
+}
+
+extern "C" int64_t aptai_gemm_workspace_bytes(int64_t M, int64_t N, int split_k) {
+    return (int64_t)(split_k > 0 ? split_k : 1) * M * N * 4;
+}

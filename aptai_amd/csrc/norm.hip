@@ -1,0 +1,208 @@
+// LayerNorm forward/backward over the channel axis of channels-last bf16 activations (gfx950).
+// Replaces nn.LayerNorm at HF:288-299 (conv-stack LN, large), HF:425-431 (feature projection),
+// HF:587-601 / 622-644 (encoder layers), HF:691 / 791 (encoder LN) and models/modules.py:134,151.
+// HBM-bound: one wave64 per row, 8-byte vector loads, statistics in fp32 with wave shuffles, no LDS
+// on the forward path.  Algorithmic bytes/row: 2*cols in + 2*cols out (+8 for mean/rstd).
+#include "common.h"
+
+namespace {
+
+template <int NCH>   // cols = NCH * 256
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                     float eps, int gelu_after) {
+    constexpr int COLS = NCH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gm[NCH][4], bt[NCH][4];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const f32x4 g4 = *(const f32x4*)(gamma + (j * 64 + lane) * 4);
+        const f32x4 b4 = *(const f32x4*)(beta + (j * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { gm[j][r] = g4[r]; bt[j][r] = b4[r]; }
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const bf16_t* xr = x + row * COLS;
+        float v[NCH][4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const u32x2 p = *(const u32x2*)(xr + (j * 64 + lane) * 4);
+            v[j][0] = lo_bf(p[0]); v[j][1] = hi_bf(p[0]); v[j][2] = lo_bf(p[1]); v[j][3] = hi_bf(p[1]);
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        const float mu = wave_sum(s) * (1.0f / COLS);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = v[j][r] - mu; q += d * d; }
+        const float rs = rsqrtf(wave_sum(q) * (1.0f / COLS) + eps);
+        bf16_t* yr = y + row * COLS;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = (v[j][r] - mu) * rs * gm[j][r] + bt[j][r];
+                if (gelu_after) o[r] = gelu_erf(o[r]);
+            }
+            *(u32x2*)(yr + (j * 64 + lane) * 4) = (u32x2){pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        }
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+    }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) [+ dres];  partial dgamma/dbeta per block.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const bf16_t* __restrict__ dres,
+                                                     bf16_t* __restrict__ dx, bf16_t* __restrict__ dx_drop,
+                                                     uint32_t seed0, uint32_t seed1, uint32_t thr16, float dscale,
+                                                     float* __restrict__ partials, long rows) {
+    constexpr int COLS = NCH * 256;
+    __shared__ float red[4][2][COLS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gm[NCH][4], dg[NCH][4], db[NCH][4];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const f32x4 g4 = *(const f32x4*)(gamma + (j * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { gm[j][r] = g4[r]; dg[j][r] = 0.f; db[j][r] = 0.f; }
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[NCH][4], gd[NCH][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const long off = row * COLS + (j * 64 + lane) * 4;
+            const u32x2 px = *(const u32x2*)(x + off);
+            const u32x2 pd = *(const u32x2*)(dy + off);
+            const float xv[4] = {lo_bf(px[0]), hi_bf(px[0]), lo_bf(px[1]), hi_bf(px[1])};
+            const float dv[4] = {lo_bf(pd[0]), hi_bf(pd[0]), lo_bf(pd[1]), hi_bf(pd[1])};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xh[j][r] = (xv[r] - mu) * rs;
+                gd[j][r] = dv[r] * gm[j][r];
+                s1 += gd[j][r];
+                s2 += gd[j][r] * xh[j][r];
+                dg[j][r] += dv[r] * xh[j][r];
+                db[j][r] += dv[r];
+            }
+        }
+        s1 = wave_sum(s1) * (1.0f / COLS);
+        s2 = wave_sum(s2) * (1.0f / COLS);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const long off = row * COLS + (j * 64 + lane) * 4;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = rs * (gd[j][r] - s1 - xh[j][r] * s2);
+            if (dres) {
+                const u32x2 pr = *(const u32x2*)(dres + off);
+                o[0] += lo_bf(pr[0]); o[1] += hi_bf(pr[0]); o[2] += lo_bf(pr[1]); o[3] += hi_bf(pr[1]);
+            }
+            *(u32x2*)(dx + off) = (u32x2){pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            if (dx_drop) {
+                float m[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    m[r] = drop_keep((uint64_t)off + r, seed0, seed1, thr16) ? o[r] * dscale : 0.f;
+                *(u32x2*)(dx_drop + off) = (u32x2){pack2bf(m[0], m[1]), pack2bf(m[2], m[3])};
+            }
+        }
+    }
+    // block reduction of the per-wave column partials
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[wave][0][(j * 64 + lane) * 4 + r] = dg[j][r];
+            red[wave][1][(j * 64 + lane) * 4 + r] = db[j][r];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * COLS; c += 256) {
+        const int which = c / COLS, col = c % COLS;
+        const float s = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+        partials[((long)blockIdx.x * 2 + which) * COLS + col] = s;
+    }
+}
+
+// out[which][col] = sum_b partials[b][which][col]
+__global__ void colsum_partials_kernel(const float* __restrict__ partials, float* __restrict__ out0,
+                                       float* __restrict__ out1, int nblocks, int cols) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * cols) return;
+    const int which = c / cols, col = c % cols;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partials[((long)b * 2 + which) * cols + col];
+    float* o = which ? out1 : out0;
+    if (o) o[col] = s;
+}
+
+constexpr int LN_BWD_MAX_BLOCKS = 512;
+
+}  // namespace
+
+extern "C" int aptai_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                   float* rstd, int64_t rows, int64_t cols, float eps, int gelu_after, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APTAI_REQUIRE(x && gamma && beta && y, "aptai_layernorm_fwd: null pointer");
+    APTAI_REQUIRE(rows > 0, "aptai_layernorm_fwd: rows=%ld", (long)rows);
+    APTAI_REQUIRE(cols % 256 == 0 && cols >= 256 && cols <= 1024, "aptai_layernorm_fwd: cols=%ld (need 256..1024, %%256)", (long)cols);
+    long blocks = ceil_div(rows, 4);
+    if (blocks > 2048) blocks = 2048;
+#define LN_FWD(NCH) hipLaunchKernelGGL(ln_fwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, (long)rows, eps, gelu_after)
+    switch (cols / 256) {
+        case 1: LN_FWD(1); break;
+        case 2: LN_FWD(2); break;
+        case 3: LN_FWD(3); break;
+        default: LN_FWD(4); break;
+    }
+#undef LN_FWD
+    APTAI_CHECK_LAUNCH("ln_fwd_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int64_t aptai_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols) {
+    long blocks = ceil_div(rows, 4);
+    if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
+    return blocks * 2 * cols * 4;
+}
+
+extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
+                                   const float* gamma, const void* dres, void* dx, void* dx_drop, float dropout_p,
+                                   uint64_t seed, float* dgamma, float* dbeta, void* workspace, int64_t rows,
+                                   int64_t cols, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APTAI_REQUIRE(dy && x && mean && rstd && gamma && dx && workspace, "aptai_layernorm_bwd: null pointer");
+    APTAI_REQUIRE(cols % 256 == 0 && cols >= 256 && cols <= 1024, "aptai_layernorm_bwd: cols=%ld", (long)cols);
+    APTAI_REQUIRE(rows > 0, "aptai_layernorm_bwd: rows=%ld", (long)rows);
+    long blocks = ceil_div(rows, 4);
+    if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
+    const uint32_t thr = drop_thr16(dropout_p);
+    void* dxd = thr ? dx_drop : nullptr;
+    if (dx_drop && !thr) APTAI_FAIL(APTAI_ERR_INVALID, "aptai_layernorm_bwd: dx_drop given with dropout_p == 0");
+#define LN_BWD(NCH) hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows)
+    switch (cols / 256) {
+        case 1: LN_BWD(1); break;
+        case 2: LN_BWD(2); break;
+        case 3: LN_BWD(3); break;
+        default: LN_BWD(4); break;
+    }
+#undef LN_BWD
+    APTAI_CHECK_LAUNCH("ln_bwd_kernel");
+    if (dgamma || dbeta) {
+        const int n = 2 * (int)cols;
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+                           (const float*)workspace, dgamma, dbeta, (int)blocks, (int)cols);
+        APTAI_CHECK_LAUNCH("colsum_partials_kernel");
+    }
+    return APTAI_OK;
+}

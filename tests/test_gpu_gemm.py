@@ -1,0 +1,156 @@
+"""GPU parity: aptai_gemm_bf16 (NT / NN / TN, epilogues, split-K) against fp32 torch on the CPU.
+
+Inputs are rounded to bf16 first, so the only differences are fp32 accumulation order and the final
+bf16 rounding of the output (rel 2^-8): tolerance 1e-2 * scale.  Integer-valued cases must be exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _rand(shape, g, scale=1.0):
+    return _bf(torch.randn(shape, generator=g) * scale)
+
+
+def _cmp(got, ref, tol=1e-2):
+    got = got.float().cpu()
+    scale = ref.abs().max().item() + 1e-6
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"max err {err} vs scale {scale}"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from aptai_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 768, 512), (1000, 768, 768), (499, 2304, 768),
+                                   (130, 136, 192), (8192, 768, 3072)])
+def test_nt_plain(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = _rand((M, K), g), _rand((N, K), g)
+    out = ops.gemm(a.cuda(), b.cuda(), M, N, K)
+    _cmp(out, a.float() @ b.float().t())
+
+
+def test_nt_exact_identity_asymmetric():
+    from aptai_amd import ops
+    M = N = K = 256
+    a = torch.eye(M)
+    b = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] % 7).float() % 251   # asymmetric, exact in bf16
+    out = ops.gemm(_bf(a).cuda(), _bf(b).cuda(), M, N, K)
+    assert torch.equal(out.float().cpu(), _bf(b).float().t())
+
+
+def test_nt_strided_rows_conv_like(ops):
+    """Implicit-GEMM conv: overlapping A rows, lda = 2*C < K = 3*C (HF conv layer k=3, s=2)."""
+    g = torch.Generator().manual_seed(3)
+    C, Tout = 128, 300
+    x = _rand((2 * Tout + 2, C), g)
+    w = _rand((256, 3 * C), g, 0.1)
+    out = ops.gemm(x.cuda(), w.cuda(), Tout, 256, 3 * C, lda=2 * C, gelu=True)
+    A = torch.stack([x[2 * t:2 * t + 3].reshape(-1) for t in range(Tout)]).float()
+    _cmp(out, torch.nn.functional.gelu(A @ w.float().t()))
+
+
+def test_nt_epilogues(ops):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 777, 768, 256
+    a, b = _rand((M, K), g), _rand((N, K), g, 0.1)
+    bias = torch.randn(N, generator=g)
+    res = _rand((M, N), g)
+    aux = _rand((M, N), g)
+    A, B = a.float(), b.float()
+    base = A @ B.t() + bias
+    out_pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm(a.cuda(), b.cuda(), M, N, K, bias=bias.cuda(), gelu=True, out_pre=out_pre)
+    _cmp(out_pre, base)
+    _cmp(out, torch.nn.functional.gelu(base))
+    out = ops.gemm(a.cuda(), b.cuda(), M, N, K, bias=bias.cuda(), residual=res.cuda())
+    _cmp(out, base + res.float())
+    out = ops.gemm(a.cuda(), b.cuda(), M, N, K, dgelu_aux=aux.cuda(), residual=res.cuda())
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    _cmp(out, (A @ B.t()) * x.grad + res.float())
+    out = ops.gemm(a.cuda(), b.cuda(), M, N, K, alpha=0.125)
+    _cmp(out, 0.125 * (A @ B.t()))
+
+
+def test_nt_dropout_mask_is_reproducible_and_unbiased(ops):
+    g = torch.Generator().manual_seed(6)
+    M, N, K = 1024, 768, 64
+    a, b = _rand((M, K), g), _rand((N, K), g)
+    ref = a.float() @ b.float().t()
+    o1 = ops.gemm(a.cuda(), b.cuda(), M, N, K, dropout_p=0.1, seed=1234).float().cpu()
+    o2 = ops.gemm(a.cuda(), b.cuda(), M, N, K, dropout_p=0.1, seed=1234).float().cpu()
+    o3 = ops.gemm(a.cuda(), b.cuda(), M, N, K, dropout_p=0.1, seed=99).float().cpu()
+    assert torch.equal(o1, o2)
+    keep = o1 != 0
+    rate = 1.0 - keep.float().mean().item()
+    assert abs(rate - 0.1) < 0.003, rate
+    assert (keep != (o3 != 0)).float().mean().item() > 0.1          # different seed, different mask
+    scale = 65536.0 / (65536.0 - round(0.1 * 65536))
+    _cmp(o1[keep], ref[keep] * scale)
+    # rows / columns are not correlated: per-column keep rate stays near 0.9
+    assert (keep.float().mean(0) - 0.9).abs().max().item() < 0.05
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 768, 3072), (1000, 512, 128), (499, 3072, 768)])
+def test_nn_dgrad(ops, M, N, K):
+    """dX[M,N] = dY[M,K] . W[K,N]   (B stored K-major)."""
+    g = torch.Generator().manual_seed(7 + M)
+    dy, w = _rand((M, K), g), _rand((K, N), g, 0.1)
+    res = _rand((M, N), g)
+    out = ops.gemm(dy.cuda(), w.cuda(), M, N, K, b_kmajor=True, residual=res.cuda())
+    _cmp(out, dy.float() @ w.float() + res.float())
+
+
+def test_nn_exact_integer(ops):
+    M, N, K = 128, 256, 128
+    dy = (torch.arange(M)[:, None] == torch.arange(K)[None, :]).float() * 2.0     # 2*I
+    w = ((torch.arange(K)[:, None] * 5 + torch.arange(N)[None, :] * 3) % 127).float()
+    out = ops.gemm(_bf(dy).cuda(), _bf(w).cuda(), M, N, K, b_kmajor=True)
+    assert torch.equal(out.float().cpu(), (2.0 * w))
+
+
+@pytest.mark.parametrize("M,N,K,S", [(768, 768, 1024, 1), (2304, 768, 2048, 4), (768, 3072, 8192, 2),
+                                     (512, 1536, 640, 3), (40, 768, 512, 2)])
+def test_tn_wgrad(ops, M, N, K, S):
+    """dW[M,N] = dY[K,M]^T . X[K,N] (both K-major), fp32 out, split-K slabs, accumulate."""
+    g = torch.Generator().manual_seed(11 + M + S)
+    dy, x = _rand((K, M), g), _rand((K, N), g)
+    ref = dy.float().t() @ x.float()
+    out = ops.gemm(dy.cuda(), x.cuda(), M, N, K, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=S)
+    _cmp(out, ref, tol=2e-5 * K ** 0.5)
+    prev = torch.randn(M, N, generator=g)
+    acc = prev.clone().cuda()
+    ops.gemm(dy.cuda(), x.cuda(), M, N, K, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=S, out=acc,
+             accumulate=True)
+    _cmp(acc, ref + prev, tol=2e-5 * K ** 0.5)
+
+
+def test_tn_strided_operand(ops):
+    """conv wgrad: X operand has overlapping rows (ldb = 2*C, N = 3*C)."""
+    g = torch.Generator().manual_seed(13)
+    C, T = 128, 512
+    x = _rand((2 * T + 2, C), g)
+    dy = _rand((T, 256), g)
+    out = ops.gemm(dy.cuda(), x.cuda(), 256, 3 * C, T, a_kmajor=True, b_kmajor=True, out_f32=True, ldb=2 * C)
+    A = torch.stack([x[2 * t:2 * t + 3].reshape(-1) for t in range(T)]).float()
+    _cmp(out, dy.float().t() @ A, tol=1e-3)
+
+
+def test_bad_arguments_fail_loudly(ops):
+    from aptai_amd._lib import AptaiHipError
+    a = torch.zeros(128, 100, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(AptaiHipError):
+        ops.gemm(a, a, 128, 128, 100)              # K not a multiple of 64
+    with pytest.raises(AptaiHipError):
+        ops.gemm(a.cpu(), a.cpu(), 128, 128, 64)   # CPU tensors: no fallback
