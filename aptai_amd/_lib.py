@@ -42,7 +42,9 @@ def lib() -> ctypes.CDLL:
                         f"or `make -C {CSRC}` — aptai_amd has no CPU fallback")
                 L = ctypes.CDLL(LIB_PATH)
                 L.aptai_last_error.restype = ctypes.c_char_p
-                L.aptai_gemm_workspace_bytes.restype = ctypes.c_int64
+                for fn in declared_symbols():
+                    if fn.endswith('_workspace_bytes'):
+                        getattr(L, fn).restype = ctypes.c_int64
                 _lib = L
     return _lib
 

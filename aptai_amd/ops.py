@@ -83,3 +83,63 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     _lib.check(_lib.lib().aptai_gemm_bf16(ctypes.byref(d), c_void_p(_stream())), "aptai_gemm_bf16")
     return out
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x, gamma, beta, eps, *, gelu_after=False, save_stats=True, out=None):
+    _dev(x, gamma, beta)
+    rows, cols = x.shape[0], x.shape[1]
+    y = out if out is not None else torch.empty_like(x)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().aptai_layernorm_fwd(c_void_p(x.data_ptr()), c_void_p(gamma.data_ptr()),
+                                              c_void_p(beta.data_ptr()), c_void_p(y.data_ptr()), c_void_p(_ptr(mean)),
+                                              c_void_p(_ptr(rstd)), c_i64(rows), c_i64(cols), c_float(eps),
+                                              c_int(int(gelu_after)), c_void_p(_stream())), "aptai_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, dres=None, dropout_p=0.0, seed=0, need_param_grads=True):
+    """Returns (dx, dx_drop | None, dgamma | None, dbeta | None)."""
+    _dev(dy, x, mean, rstd, gamma, dres)
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    dx_drop = torch.empty_like(x) if dropout_p > 0 else None
+    dgamma = dbeta = None
+    if need_param_grads:
+        dgamma = torch.empty(cols, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(cols, device=x.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().aptai_layernorm_bwd_workspace_bytes(c_i64(rows), c_i64(cols)), device=x.device,
+                     dtype=torch.uint8)
+    _lib.check(_lib.lib().aptai_layernorm_bwd(
+        c_void_p(dy.data_ptr()), c_void_p(x.data_ptr()), c_void_p(mean.data_ptr()), c_void_p(rstd.data_ptr()),
+        c_void_p(gamma.data_ptr()), c_void_p(_ptr(dres)), c_void_p(dx.data_ptr()), c_void_p(_ptr(dx_drop)),
+        c_float(dropout_p), c_u64(seed), c_void_p(_ptr(dgamma)), c_void_p(_ptr(dbeta)), c_void_p(ws.data_ptr()),
+        c_i64(rows), c_i64(cols), c_void_p(_stream())), "aptai_layernorm_bwd")
+    return dx, dx_drop, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------- attention
+def attention_fwd(qkv, lens_i32, B, Tp, H, heads, *, dropout_p=0.0, seed=0, save_lse=True):
+    _dev(qkv, lens_i32)
+    ctx = torch.empty((B * Tp, H), device=qkv.device, dtype=torch.bfloat16)
+    lse2 = torch.empty((B, heads, Tp), device=qkv.device, dtype=torch.float32) if save_lse else None
+    _lib.check(_lib.lib().aptai_attention_fwd(
+        c_void_p(qkv.data_ptr()), c_void_p(lens_i32.data_ptr()), c_void_p(ctx.data_ptr()), c_void_p(_ptr(lse2)),
+        c_i64(B), c_i64(Tp), c_i64(H), c_i64(heads), c_float((H // heads) ** -0.5), c_float(dropout_p), c_u64(seed),
+        c_void_p(_stream())), "aptai_attention_fwd")
+    return ctx, lse2
+
+
+def attention_bwd(qkv, lens_i32, ctx, dctx, lse2, B, Tp, H, heads, *, dropout_p=0.0, seed=0, dctx_zero_beyond_len=False):
+    _dev(qkv, lens_i32, ctx, dctx, lse2)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, heads, Tp), device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.lib().aptai_attention_bwd(
+        c_void_p(qkv.data_ptr()), c_void_p(lens_i32.data_ptr()), c_void_p(ctx.data_ptr()), c_void_p(dctx.data_ptr()),
+        c_void_p(lse2.data_ptr()), c_void_p(delta.data_ptr()), c_void_p(dqkv.data_ptr()), c_i64(B), c_i64(Tp),
+        c_i64(H), c_i64(heads), c_float((H // heads) ** -0.5), c_float(dropout_p), c_u64(seed),
+        c_int(int(dctx_zero_beyond_len)), c_void_p(_stream())), "aptai_attention_bwd")
+    return dqkv

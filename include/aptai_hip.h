@@ -69,6 +69,32 @@ typedef struct {
 int aptai_gemm_bf16(const aptai_gemm_desc* desc, void* stream);
 int64_t aptai_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
 
+/* ------------------------------------------------------------------------------------------------ LayerNorm
+ * y = (x - mean) * rstd * gamma + beta over the channel axis (cols in {256,512,768,1024}), one wave per row.
+ * Replaces nn.LayerNorm at HF:288-299 (conv layers, "layer" mode; gelu_after=1 fuses the GELU of HF:299),
+ * HF:425-431, HF:587-601 / 622-644, HF:691 / 791 and models/modules.py:134,151.  x,y bf16; mean/rstd fp32 (may be null). */
+int aptai_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                        int64_t rows, int64_t cols, float eps, int gelu_after, void* stream);
+/* dx = LN'(dy) [+ dres]; optional dx_drop = dropout-masked copy of dx (mask of (seed, element index), for the
+ * branch that went through nn.Dropout, HF:591,628); dgamma/dbeta fp32 [cols] (overwritten). */
+int aptai_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                        const void* dres, void* dx, void* dx_drop, float dropout_p, uint64_t seed, float* dgamma,
+                        float* dbeta, void* workspace, int64_t rows, int64_t cols, void* stream);
+int64_t aptai_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
+
+/* ------------------------------------------------------------------------------------------------ attention
+ * softmax(Q K^T * scale + key-padding mask) V per head (head_dim 64), flash-style, replacing HF:452-461 / sdpa
+ * as called from HF:522-546, and its backward.  qkv [B*Tp][3H] bf16; lens int32 [B] valid frames (keys beyond are
+ * masked, HF:678-688); Tp % 128 == 0; ctx [B*Tp][H] bf16; lse2 fp32 [B][heads][Tp] (log2-domain log-sum-exp).
+ * dropout_p: attention-probability dropout (HF:458), mask from (seed, (b,h,q,k)). */
+int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* ctx, float* lse2, int64_t B, int64_t Tp, int64_t H,
+                        int64_t heads, float scale, float dropout_p, uint64_t seed, void* stream);
+/* delta_ws: fp32 [B][heads][Tp] scratch.  dctx_zero_beyond_len=1 lets the kernel skip query rows >= lens[b]
+ * (their incoming gradient is exactly zero in the models: no loss term touches padded frames). */
+int aptai_attention_bwd(const void* qkv, const int32_t* lens, const void* ctx, const void* dctx, const float* lse2,
+                        float* delta_ws, void* dqkv, int64_t B, int64_t Tp, int64_t H, int64_t heads, float scale,
+                        float dropout_p, uint64_t seed, int dctx_zero_beyond_len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

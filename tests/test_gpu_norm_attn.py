@@ -1,0 +1,130 @@
+"""GPU parity: LayerNorm fwd/bwd and the attention core fwd/bwd against fp32 torch on the CPU
+(inputs pre-rounded to bf16; outputs are bf16 -> tolerance 1e-2 of the tensor scale unless noted)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _cmp(got, ref, tol=1e-2, name=""):
+    got = got.float().cpu()
+    scale = ref.abs().max().item() + 1e-6
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"{name}: max err {err} vs scale {scale}"
+
+
+@pytest.mark.parametrize("rows,cols", [(37, 256), (1000, 512), (4099, 768), (8192, 1024)])
+def test_layernorm_fwd_bwd(rows, cols):
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    x = _bf(torch.randn(rows, cols, generator=g) * 2 + 0.5)
+    gamma = 1 + 0.1 * torch.randn(cols, generator=g)
+    beta = 0.1 * torch.randn(cols, generator=g)
+    dy = _bf(torch.randn(rows, cols, generator=g))
+    dres = _bf(torch.randn(rows, cols, generator=g))
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (cols,), gr, br, 1e-5)
+    yr.backward(dy.float())
+    y, mean, rstd = ops.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5)
+    _cmp(y, yr.detach(), name="y")
+    _cmp(mean, x.float().mean(-1), tol=1e-5, name="mean")
+    dx, dxd, dgam, dbet = ops.layernorm_bwd(dy.cuda(), x.cuda(), mean, rstd, gamma.cuda(), dres=dres.cuda())
+    assert dxd is None
+    _cmp(dx, xr.grad + dres.float(), name="dx")
+    _cmp(dgam, gr.grad, tol=2e-3, name="dgamma")
+    _cmp(dbet, br.grad, tol=2e-3, name="dbeta")
+    # fused GELU-after variant (conv stack of the large model)
+    y2, _, _ = ops.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5, gelu_after=True, save_stats=False)
+    _cmp(y2, F.gelu(yr.detach()), name="gelu(y)")
+    # dropout-masked second output: same values where kept (scaled), zeros elsewhere, ~p dropped
+    dx1, dxd, _, _ = ops.layernorm_bwd(dy.cuda(), x.cuda(), mean, rstd, gamma.cuda(), dropout_p=0.1, seed=5,
+                                       need_param_grads=False)
+    keep = dxd.float() != 0
+    assert abs(1 - keep.float().mean().item() - 0.1) < 0.01
+    scale = 65536.0 / (65536.0 - round(0.1 * 65536))
+    _cmp(dxd.float()[keep], (dx1.float() * scale)[keep].cpu(), tol=1e-2, name="dx_drop")
+
+
+def _attn_ref(qkv, lens, B, Tp, H, heads):
+    d = H // heads
+    q, k, v = qkv.float().view(B, Tp, 3, heads, d).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * d ** -0.5
+    mask = torch.arange(Tp)[None, :] < lens[:, None]
+    s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * Tp, H), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,Tp,heads,lens", [(2, 128, 2, [128, 77]), (3, 256, 12, [256, 200, 1]),
+                                            (2, 512, 16, [499, 410]), (1, 1536, 2, [1499])])
+def test_attention_fwd_bwd(B, Tp, heads, lens):
+    from aptai_amd import ops
+    H = heads * 64
+    g = torch.Generator().manual_seed(B * Tp + heads)
+    qkv = _bf(torch.randn(B * Tp, 3 * H, generator=g))
+    dctx = _bf(torch.randn(B * Tp, H, generator=g))
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    qr = qkv.float().requires_grad_(True)
+    ctx_ref, lse_ref = _attn_ref(qr, lens_t, B, Tp, H, heads)
+    ctx_ref.backward(dctx.float())
+    ctx, lse2 = ops.attention_fwd(qkv.cuda(), lens_t.cuda(), B, Tp, H, heads)
+    _cmp(ctx, ctx_ref.detach(), name="ctx")
+    _cmp(lse2 * 0.6931471805599453, lse_ref.detach(), tol=2e-3, name="lse")
+    dqkv = ops.attention_bwd(qkv.cuda(), lens_t.cuda(), ctx, dctx.cuda(), lse2, B, Tp, H, heads)
+    ref = qr.grad.view(B * Tp, 3, H)
+    got = dqkv.float().cpu().view(B * Tp, 3, H)
+    for i, n in enumerate(("dQ", "dK", "dV")):
+        _cmp(got[:, i], ref[:, i], tol=1.5e-2, name=n)
+    # padded keys receive exactly zero gradient
+    for b, L in enumerate(lens):
+        assert got[b * Tp + L:(b + 1) * Tp, 1:].abs().max().item() == 0 if L < Tp else True
+    # with dctx zeroed beyond the utterance, skipping those query rows is exact
+    dz = dctx.clone().view(B, Tp, H)
+    for b, L in enumerate(lens):
+        dz[b, L:] = 0
+    dz = dz.view(B * Tp, H)
+    full = ops.attention_bwd(qkv.cuda(), lens_t.cuda(), ctx, dz.cuda(), lse2, B, Tp, H, heads)
+    skip = ops.attention_bwd(qkv.cuda(), lens_t.cuda(), ctx, dz.cuda(), lse2, B, Tp, H, heads, dctx_zero_beyond_len=True)
+    valid = torch.zeros(B, Tp, dtype=torch.bool)
+    for b, L in enumerate(lens):
+        valid[b, :L] = True
+    valid = valid.view(-1)
+    assert torch.equal(full[valid.cuda()][:, :], skip[valid.cuda()][:, :])
+
+
+def test_attention_dropout_consistency():
+    """Dropout on P: forward/backward regenerate the same mask -> finite-difference-free check against an
+    explicit-mask reference is impossible without the mask, so check (a) determinism in the seed, (b) mean
+    preservation, (c) gradient consistency: d<ctx,w>/dV matches  P_drop^T w  recomputed through the V linearity."""
+    from aptai_amd import ops
+    B, Tp, heads = 2, 256, 4
+    H = heads * 64
+    g = torch.Generator().manual_seed(1)
+    qkv = _bf(torch.randn(B * Tp, 3 * H, generator=g))
+    lens = torch.tensor([256, 190], dtype=torch.int32)
+    c0, _ = ops.attention_fwd(qkv.cuda(), lens.cuda(), B, Tp, H, heads)
+    c1, l1 = ops.attention_fwd(qkv.cuda(), lens.cuda(), B, Tp, H, heads, dropout_p=0.1, seed=42)
+    c2, _ = ops.attention_fwd(qkv.cuda(), lens.cuda(), B, Tp, H, heads, dropout_p=0.1, seed=42)
+    c3, _ = ops.attention_fwd(qkv.cuda(), lens.cuda(), B, Tp, H, heads, dropout_p=0.1, seed=43)
+    assert torch.equal(c1, c2) and not torch.equal(c1, c3)
+    rel = ((c1.float() - c0.float()).norm() / c0.float().norm()).item()
+    assert 0.05 < rel < 1.5, rel
+    # ctx is linear in V for a fixed mask: ctx(V1+V2) = ctx(V1)+ctx(V2)  (bf16 rounding tolerance)
+    q2 = qkv.clone().view(B * Tp, 3, H)
+    q2[:, 2] = q2[:, 2] * 2
+    c4, _ = ops.attention_fwd(q2.view(B * Tp, 3 * H).cuda(), lens.cuda(), B, Tp, H, heads, dropout_p=0.1, seed=42)
+    _cmp(c4, 2 * c1.float().cpu(), tol=2e-2, name="linearity in V under a fixed mask")
+    # backward: dV = P_drop^T dctx.  <dV, V> must equal <dctx, ctx> (Euler identity for the V-linear map)
+    dctx = _bf(torch.randn(B * Tp, H, generator=g))
+    dqkv = ops.attention_bwd(qkv.cuda(), lens.cuda(), c1, dctx.cuda(), l1, B, Tp, H, heads, dropout_p=0.1, seed=42)
+    dV = dqkv.float().cpu().view(B * Tp, 3, H)[:, 2]
+    V = qkv.float().view(B * Tp, 3, H)[:, 2]
+    lhs = (dV * V).sum().item()
+    rhs = (dctx.float() * c1.float().cpu()).sum().item()
+    assert abs(lhs - rhs) <= 2e-2 * (abs(rhs) + 50), (lhs, rhs)
