@@ -18,6 +18,36 @@ LIB_PATH = os.path.join(CSRC, "libaptai_hip.so")
 _lib = None
 _lock = threading.Lock()
 
+_P, _I64, _I, _F, _U64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_uint64
+# argument types of every entry point except aptai_gemm_bf16 (descriptor struct, see ops.GemmDesc)
+ARGTYPES = {
+    "aptai_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I, _P],
+    "aptai_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _P, _P, _P, _I64, _I64, _P],
+    "aptai_layernorm_bwd_workspace_bytes": [_I64, _I64],
+    "aptai_attention_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _U64, _P],
+    "aptai_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _U64, _I, _P],
+    "aptai_cast_f32_to_bf16": [_P, _P, _I64, _I64, _I64, _P],
+    "aptai_conv_weight_to_bf16": [_P, _P, _I64, _I64, _I64, _P],
+    "aptai_posconv_weight": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
+    "aptai_posconv_pack": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _P],
+    "aptai_frame_mask_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "aptai_frame_mask_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "aptai_frame_mask_bwd_workspace_bytes": [_I64, _I64, _I64],
+    "aptai_colsum_bf16": [_P, _I64, _P, _P, _I64, _I64, _I, _P],
+    "aptai_colsum_workspace_bytes": [_I64, _I64],
+    "aptai_dropout_bf16": [_P, _P, _I64, _F, _U64, _P],
+    "aptai_conv0_fwd": [_P, _I64, _I64, _P, _P, _P, _P, _I, _F, _P, _I64, _I64, _I64, _I64, _I64, _P, _P],
+    "aptai_conv0_workspace_bytes": [_I64, _I64],
+    "aptai_head_act_fwd": [_P, _P, _P, _I64, _F, _F, _U64, _P],
+    "aptai_head_act_bwd": [_P, _P, _P, _P, _I64, _F, _F, _U64, _P],
+    "aptai_lowpass_fir": [_P, _I64, _I64, _P, _I64, _P, _I64, _I64, _I, _I64, _I64, _I64, _I64, _I64, _P],
+    "aptai_aptai_loss_fwd": [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _F, _F, _P, _P, _P, _P],
+    "aptai_aptai_loss_bwd": [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _F, _F, _P, _P, _P, _P, _I64, _P],
+    "aptai_aptai_loss_workspace_bytes": [],
+    "aptai_gemm_workspace_bytes": [_I64, _I64, _I],
+    "aptai_device_check": [ctypes.c_char_p, _I],
+}
+
 
 class AptaiHipError(RuntimeError):
     pass
@@ -45,8 +75,15 @@ def lib() -> ctypes.CDLL:
                 for fn in declared_symbols():
                     if fn.endswith('_workspace_bytes'):
                         getattr(L, fn).restype = ctypes.c_int64
+                    if fn in ARGTYPES:
+                        getattr(L, fn).argtypes = ARGTYPES[fn]
                 _lib = L
     return _lib
+
+
+def call(name: str, *args) -> None:
+    """Call an int-returning entry point with its declared argtypes and raise on a non-zero status."""
+    check(getattr(lib(), name)(*args), name)
 
 
 def check(rc: int, what: str = "") -> None:

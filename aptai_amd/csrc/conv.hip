@@ -1,0 +1,205 @@
+// First layer of the wav2vec2 feature encoder on the raw waveform (HF:260-266 conv, C_in=1 -> 512, k=10, s=5),
+// fused with its normalisation and GELU so the 32.8 MB/utterance (10 s) activation is written exactly once:
+//   mode 0 "group": GroupNorm(512 groups of 1 channel) over all T0 frames (HF:317-323, wav2vec2-base)
+//                   -> pass 1 recomputes the conv to get per-(utterance, channel) statistics, pass 2 writes.
+//   mode 1 "layer": LayerNorm(512) over channels per frame (HF:288-299, wav2vec2-large), single pass.
+// HBM-bound by the output write (512 ch x 2 B per frame; the waveform read is 20 B per frame).
+// One wave per frame, lane = 8 consecutive channels (16-byte coalesced stores); weights live in registers.
+// Layers 1..6 are strided-row implicit GEMMs (gemm.hip).
+#include "common.h"
+
+namespace {
+
+constexpr int C0 = 512, KW = 10, STRIDE = 5;
+constexpr int FRAMES_PER_BLOCK_STATS = 256;
+
+struct Conv0Args {
+    const float* audio; long S;
+    const float* w; const float* bias; const float* gamma; const float* beta;
+    bf16_t* out;
+    int B, T_real, T_alloc;
+    float eps;
+    float* partials;       // [B][nchunks][2][512]
+    const float* stats;    // [B][2][512]  (mean, rstd)
+    int nchunks;
+};
+
+__device__ __forceinline__ void load_weights(const Conv0Args& a, int lane, float (&w)[8][KW], float (&bias)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane * 8 + j;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) w[j][k] = a.w[c * KW + k];
+        bias[j] = a.bias ? a.bias[c] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void conv_frame(const float* __restrict__ x, const float (&w)[8][KW], const float (&bias)[8],
+                                           float (&v)[8]) {
+    float s[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) s[k] = x[k];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float acc = bias[j];
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc = fmaf(s[k], w[j][k], acc);
+        v[j] = acc;
+    }
+}
+
+__device__ __forceinline__ void store8(bf16_t* dst, const float (&o)[8]) {
+    *(u32x4*)dst = (u32x4){pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+}
+
+// ---- mode 1: conv + bias -> LayerNorm(512) -> GELU, one pass.  grid (blocks, B)
+__global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    float w[8][KW], bias[8], gm[8], bt[8];
+    load_weights(a, lane, w, bias);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gm[j] = a.gamma[lane * 8 + j]; bt[j] = a.beta[lane * 8 + j]; }
+    const float* xb = a.audio + (long)b * a.S;
+    bf16_t* ob = a.out + (long)b * a.T_alloc * C0;
+    for (int t = blockIdx.x * 4 + wave; t < a.T_alloc; t += gridDim.x * 4) {
+        float o[8];
+        if (t < a.T_real) {
+            float v[8];
+            conv_frame(xb + (long)t * STRIDE, w, bias, v);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+            const float mu = wave_sum(s) * (1.0f / C0);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[j] - mu; q += d * d; }
+            const float rs = rsqrtf(wave_sum(q) * (1.0f / C0) + a.eps);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = gelu_erf((v[j] - mu) * rs * gm[j] + bt[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        }
+        store8(ob + (long)t * C0 + lane * 8, o);
+    }
+}
+
+// ---- mode 0 pass 1: per-chunk partial sums of the conv output.  grid (nchunks, B)
+__global__ __launch_bounds__(256) void conv0_stats_kernel(Conv0Args a) {
+    __shared__ float red[4][2][C0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    float w[8][KW], bias[8];
+    load_weights(a, lane, w, bias);
+    const float* xb = a.audio + (long)b * a.S;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    const int t0 = chunk * FRAMES_PER_BLOCK_STATS;
+    int t1 = t0 + FRAMES_PER_BLOCK_STATS;
+    t1 = t1 < a.T_real ? t1 : a.T_real;
+    for (int t = t0 + wave; t < t1; t += 4) {
+        float v[8];
+        conv_frame(xb + (long)t * STRIDE, w, bias, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[wave][0][lane * 8 + j] = s1[j]; red[wave][1][lane * 8 + j] = s2[j]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C0; i += 256) {
+        const int which = i / C0, c = i % C0;
+        a.partials[(((long)b * a.nchunks + chunk) * 2 + which) * C0 + c] =
+            red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+}
+
+// ---- mode 0 finalize: mean / rstd per (b, c), combined in double.  grid (B), 512 threads
+__global__ void conv0_stats_final_kernel(const float* __restrict__ partials, float* __restrict__ stats, int nchunks,
+                                         int T_real, float eps) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+        s1 += (double)partials[(((long)b * nchunks + k) * 2 + 0) * C0 + c];
+        s2 += (double)partials[(((long)b * nchunks + k) * 2 + 1) * C0 + c];
+    }
+    const double mean = s1 / T_real;
+    double var = s2 / T_real - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    stats[((long)b * 2 + 0) * C0 + c] = (float)mean;
+    stats[((long)b * 2 + 1) * C0 + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---- mode 0 pass 2: conv -> (v - mean) * rstd * gamma + beta -> GELU.  grid (blocks, B)
+__global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    float w[8][KW], bias[8], sc[8], sh[8];
+    load_weights(a, lane, w, bias);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane * 8 + j;
+        const float mu = a.stats[((long)b * 2 + 0) * C0 + c], rs = a.stats[((long)b * 2 + 1) * C0 + c];
+        sc[j] = rs * a.gamma[c];
+        sh[j] = a.beta[c] - mu * sc[j];
+    }
+    const float* xb = a.audio + (long)b * a.S;
+    bf16_t* ob = a.out + (long)b * a.T_alloc * C0;
+    for (int t = blockIdx.x * 4 + wave; t < a.T_alloc; t += gridDim.x * 4) {
+        float o[8];
+        if (t < a.T_real) {
+            float v[8];
+            conv_frame(xb + (long)t * STRIDE, w, bias, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = gelu_erf(fmaf(v[j], sc[j], sh[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        }
+        store8(ob + (long)t * C0 + lane * 8, o);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t aptai_conv0_workspace_bytes(int64_t B, int64_t T_real) {
+    const long nchunks = ceil_div(T_real, FRAMES_PER_BLOCK_STATS);
+    return (B * nchunks * 2 * C0 + B * 2 * C0) * 4;
+}
+
+extern "C" int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias,
+                               const float* gamma, const float* beta, int mode, float eps, void* out, int64_t T_real,
+                               int64_t T_alloc, int64_t C, int64_t Kw, int64_t stride, void* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APTAI_REQUIRE(audio && weight && gamma && beta && out, "aptai_conv0_fwd: null pointer");
+    APTAI_REQUIRE(C == C0 && Kw == KW && stride == STRIDE, "aptai_conv0_fwd: built for C=512, k=10, s=5 (got %ld,%ld,%ld)",
+                  (long)C, (long)Kw, (long)stride);
+    APTAI_REQUIRE(B > 0 && T_real > 0 && T_alloc >= T_real, "aptai_conv0_fwd: bad frame counts");
+    APTAI_REQUIRE((T_real - 1) * STRIDE + KW <= S, "aptai_conv0_fwd: T_real=%ld frames need more than S=%ld samples", (long)T_real, (long)S);
+    APTAI_REQUIRE(mode == 0 || mode == 1, "aptai_conv0_fwd: mode must be 0 (group) or 1 (layer)");
+    Conv0Args a;
+    memset(&a, 0, sizeof(a));
+    a.audio = audio; a.S = S; a.w = weight; a.bias = bias; a.gamma = gamma; a.beta = beta;
+    a.out = (bf16_t*)out; a.B = (int)B; a.T_real = (int)T_real; a.T_alloc = (int)T_alloc; a.eps = eps;
+    long blocks = ceil_div(T_alloc, 4 * 8);           // 8 frames per wave
+    if (blocks > 1024) blocks = 1024;
+    if (mode == 1) {
+        hipLaunchKernelGGL(conv0_layer_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, a);
+        APTAI_CHECK_LAUNCH("conv0_layer_kernel");
+        return APTAI_OK;
+    }
+    APTAI_REQUIRE(workspace != nullptr, "aptai_conv0_fwd: group mode needs a workspace");
+    a.nchunks = (int)ceil_div(T_real, FRAMES_PER_BLOCK_STATS);
+    a.partials = (float*)workspace;
+    float* stats = (float*)workspace + (long)B * a.nchunks * 2 * C0;
+    a.stats = stats;
+    hipLaunchKernelGGL(conv0_stats_kernel, dim3((unsigned)a.nchunks, (unsigned)B), dim3(256), 0, stream, a);
+    APTAI_CHECK_LAUNCH("conv0_stats_kernel");
+    hipLaunchKernelGGL(conv0_stats_final_kernel, dim3((unsigned)B), dim3(C0), 0, stream, (const float*)a.partials, stats,
+                       a.nchunks, (int)T_real, eps);
+    APTAI_CHECK_LAUNCH("conv0_stats_final_kernel");
+    hipLaunchKernelGGL(conv0_group_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, a);
+    APTAI_CHECK_LAUNCH("conv0_group_kernel");
+    return APTAI_OK;
+}

@@ -1,0 +1,342 @@
+// HBM-bound helper kernels of the wav2vec2 hot path (gfx950): parameter casts / re-layouts, frame masking
+// (HF:678-681 zeroing of padded frames + HF:1292-1295 SpecAugment fill), bias-gradient column sums,
+// positional-conv packing (HF:326-379) and the activation shims of the APTAI heads (models/aptai.py:43-55).
+// All are grid-stride, 8/16-byte vectorised where the layout allows.
+#include "common.h"
+
+namespace {
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n4) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = ((const f32x4*)src)[i];
+        ((u32x2*)dst)[i] = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    }
+}
+
+// rows x cols fp32 -> bf16 with a destination leading dimension (packs q/k/v weights into one [3H][H] buffer)
+__global__ void cast_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long rows, long cols, long ldd) {
+    const long n = rows * cols;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long r = i / cols, c = i % cols;
+        dst[r * ldd + c] = f2bf(src[i]);
+    }
+}
+
+// conv weight [N][C][Kw] fp32 -> [N][Kw][C] bf16 (K index = kw*C + c matches channels-last frames)
+__global__ void conv_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int C, int Kw) {
+    const long n = (long)N * C * Kw;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = (int)(i % C);
+        const int kw = (int)((i / C) % Kw);
+        const int nn = (int)(i / ((long)C * Kw));
+        dst[i] = f2bf(src[((long)nn * C + c) * Kw + kw]);
+    }
+}
+
+// ---- weight-norm (dim=2) of the positional conv: norm[kk] = ||v[:, :, kk]||_2   (HF:340-356)
+__global__ void posconv_norm_kernel(const float* __restrict__ v, float* __restrict__ norm, long rows /*H*Cg*/, int Kw) {
+    __shared__ float red[256];
+    const int kk = blockIdx.x;
+    float s = 0.f;
+    for (long r = threadIdx.x; r < rows; r += blockDim.x) {
+        const float x = v[r * Kw + kk];
+        s += x * x;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) norm[kk] = sqrtf(red[0]);
+}
+
+// w = g*v/norm ->  fwd layout  Wf[grp][n][kk*Cg + c]            = w[grp*Cg+n][c][kk]
+//                  dgrad layout Wd[grp][c][kk'*Cg + n], kk'=Kw-1-kk (flipped taps, in/out swapped)
+__global__ void posconv_weight_kernel(const float* __restrict__ v, const float* __restrict__ gain,
+                                      const float* __restrict__ norm, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd,
+                                      int H, int Cg, int Kw) {
+    const long n = (long)H * Cg * Kw;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int kk = (int)(i % Kw);
+        const int c = (int)((i / Kw) % Cg);
+        const int o = (int)(i / ((long)Kw * Cg));
+        const int grp = o / Cg, nn = o % Cg;
+        const bf16_t w = f2bf(v[i] * gain[kk] / norm[kk]);
+        const long K = (long)Kw * Cg;
+        wf[((long)grp * Cg + nn) * K + (long)kk * Cg + c] = w;
+        if (wd) wd[((long)grp * Cg + c) * K + (long)(Kw - 1 - kk) * Cg + nn] = w;
+    }
+}
+
+// x [B*Tp][H] -> Xg[grp][b][pad | Tp | pad][Cg]  (gap rows are never written: the buffer is zeroed once)
+// optional: multiply by gelu'(u) first (du = dy * gelu'(u)) and also emit the row-major product.
+__global__ void posconv_pack_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ u, bf16_t* __restrict__ xg,
+                                    bf16_t* __restrict__ rowmajor_out, int B, int Tp, int H, int Cg, int pad) {
+    const long n4 = (long)B * Tp * H / 4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int G = H / Cg;
+    const long rows_p = Tp + 2 * pad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const long e = i * 4;
+        const long row = e / H;
+        const int col = (int)(e % H);
+        u32x2 p = *(const u32x2*)(x + e);
+        if (u) {
+            const u32x2 q = *(const u32x2*)(u + e);
+            p = (u32x2){pack2bf(lo_bf(p[0]) * gelu_erf_grad(lo_bf(q[0])), hi_bf(p[0]) * gelu_erf_grad(hi_bf(q[0]))),
+                        pack2bf(lo_bf(p[1]) * gelu_erf_grad(lo_bf(q[1])), hi_bf(p[1]) * gelu_erf_grad(hi_bf(q[1])))};
+            if (rowmajor_out) *(u32x2*)(rowmajor_out + e) = p;
+        }
+        const int grp = col / Cg, c = col % Cg;          // Cg % 4 == 0: the 4 elements stay in one group
+        const long b = row / Tp, t = row % Tp;
+        *(u32x2*)(xg + (((long)grp * B + b) * rows_p + pad + t) * Cg + c) = p;
+    }
+    (void)G;
+}
+
+// ---- frame masking: out = pad ? 0 : (spec ? embed : h)   (in place)
+__global__ void frame_mask_kernel(bf16_t* __restrict__ h, const int* __restrict__ lens, const uint8_t* __restrict__ spec,
+                                  const float* __restrict__ embed, int B, int Tp, int T, int H) {
+    const long n4 = (long)B * Tp * H / 4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const long e = i * 4;
+        const long row = e / H;
+        const int col = (int)(e % H);
+        const int b = (int)(row / Tp), t = (int)(row % Tp);
+        int len = lens[b];
+        len = len < T ? len : T;
+        if (t >= len) {
+            *(u32x2*)(h + e) = (u32x2){0u, 0u};
+        } else if (spec && spec[(long)b * T + t]) {
+            const f32x4 m = *(const f32x4*)(embed + col);
+            *(u32x2*)(h + e) = (u32x2){pack2bf(m[0], m[1]), pack2bf(m[2], m[3])};
+        }
+    }
+}
+
+// backward: dh = (pad | spec) ? 0 : dy (in place); dembed partials over spec & !pad rows
+__global__ void frame_mask_bwd_kernel(bf16_t* __restrict__ dy, const int* __restrict__ lens,
+                                      const uint8_t* __restrict__ spec, float* __restrict__ partials, int B, int Tp, int T,
+                                      int H, int rows_per_block) {
+    // block handles rows [blockIdx.x*rpb, +rpb); thread handles 4 columns per pass
+    const long rows = (long)B * Tp;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    for (int c4 = threadIdx.x; c4 < H / 4; c4 += blockDim.x) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int rr = 0; rr < rows_per_block; ++rr) {
+            const long row = r0 + rr;
+            if (row >= rows) break;
+            const int b = (int)(row / Tp), t = (int)(row % Tp);
+            int len = lens[b];
+            len = len < T ? len : T;
+            const long e = row * H + c4 * 4;
+            if (t >= len) {
+                *(u32x2*)(dy + e) = (u32x2){0u, 0u};
+            } else if (spec && spec[(long)b * T + t]) {
+                const u32x2 p = *(const u32x2*)(dy + e);
+                acc[0] += lo_bf(p[0]); acc[1] += hi_bf(p[0]); acc[2] += lo_bf(p[1]); acc[3] += hi_bf(p[1]);
+                *(u32x2*)(dy + e) = (u32x2){0u, 0u};
+            }
+        }
+        if (partials) *(f32x4*)(partials + (long)blockIdx.x * H + c4 * 4) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    }
+}
+
+// ---- column sums of a bf16 matrix (bias gradients): partials[block][N] then a final reduction
+__global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, float* __restrict__ partials, long rows, int N,
+                                   int rows_per_block) {
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    for (int c4 = threadIdx.x; c4 < N / 4; c4 += blockDim.x) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int rr = 0; rr < rows_per_block; ++rr) {
+            const long row = r0 + rr;
+            if (row >= rows) break;
+            const u32x2 p = *(const u32x2*)(x + row * ld + c4 * 4);
+            acc[0] += lo_bf(p[0]); acc[1] += hi_bf(p[0]); acc[2] += lo_bf(p[1]); acc[3] += hi_bf(p[1]);
+        }
+        *(f32x4*)(partials + (long)blockIdx.x * N + c4 * 4) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, float* __restrict__ out, int nblocks, int N,
+                                       int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = accumulate ? out[c] : 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partials[(long)b * N + c];
+    out[c] = s;
+}
+
+// ---- APTAI head activations: a_tv = tanh(drop(h)), a_ph = leaky_relu(drop(h))   (models/aptai.py:43-55)
+__global__ void head_act_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ a_tv, bf16_t* __restrict__ a_ph,
+                                    long n, uint32_t s0, uint32_t s1, uint32_t thr_tv, uint32_t thr_ph, float sc_tv,
+                                    float sc_ph) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float x = bf2f(h[i]);
+        float xt = x, xp = x;
+        if (thr_tv) xt = drop_keep((uint64_t)i, s0, s1, thr_tv) ? x * sc_tv : 0.f;
+        if (thr_ph) xp = drop_keep((uint64_t)i, s0 ^ 0x5bd1e995u, s1, thr_ph) ? x * sc_ph : 0.f;
+        a_tv[i] = f2bf(tanhf(xt));
+        a_ph[i] = f2bf(xp > 0.f ? xp : 0.01f * xp);
+    }
+}
+
+// dh = d_tv * (1 - tanh^2) * mask_tv + d_ph * leaky' * mask_ph
+__global__ void head_act_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ d_tv,
+                                    const bf16_t* __restrict__ d_ph, bf16_t* __restrict__ dh, long n, uint32_t s0,
+                                    uint32_t s1, uint32_t thr_tv, uint32_t thr_ph, float sc_tv, float sc_ph) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float x = bf2f(h[i]);
+        float xt = x, xp = x, mt = 1.f, mp = 1.f;
+        if (thr_tv) { mt = drop_keep((uint64_t)i, s0, s1, thr_tv) ? sc_tv : 0.f; xt = x * mt; }
+        if (thr_ph) { mp = drop_keep((uint64_t)i, s0 ^ 0x5bd1e995u, s1, thr_ph) ? sc_ph : 0.f; xp = x * mp; }
+        const float th = tanhf(xt);
+        const float g = bf2f(d_tv[i]) * (1.f - th * th) * mt + bf2f(d_ph[i]) * (xp > 0.f ? 1.f : 0.01f) * mp;
+        dh[i] = f2bf(g);
+    }
+}
+
+// generic elementwise dropout apply (forward or backward): y = keep ? x*scale : 0
+__global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n, uint32_t s0, uint32_t s1,
+                               uint32_t thr, float sc) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = drop_keep((uint64_t)i, s0, s1, thr) ? f2bf(bf2f(x[i]) * sc) : (bf16_t)0;
+}
+
+inline unsigned grid_for(long n, int block = 256, int max_blocks = 4096) {
+    long b = ceil_div(n, block);
+    return (unsigned)(b < 1 ? 1 : (b > max_blocks ? max_blocks : b));
+}
+
+}  // namespace
+
+extern "C" int aptai_cast_f32_to_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_dst, void* stream) {
+    APTAI_REQUIRE(src && dst && rows > 0 && cols > 0, "aptai_cast_f32_to_bf16: bad arguments");
+    if (ld_dst == cols && (rows * cols) % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0)) {
+        const long n4 = rows * cols / 4;
+        hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n4);
+    } else {
+        hipLaunchKernelGGL(cast_rows_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, src,
+                           (bf16_t*)dst, (long)rows, (long)cols, (long)ld_dst);
+    }
+    APTAI_CHECK_LAUNCH("cast kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_conv_weight_to_bf16(const float* src, void* dst, int64_t N, int64_t C, int64_t Kw, void* stream) {
+    APTAI_REQUIRE(src && dst && N > 0 && C > 0 && Kw > 0, "aptai_conv_weight_to_bf16: bad arguments");
+    hipLaunchKernelGGL(conv_weight_kernel, dim3(grid_for(N * C * Kw)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
+                       (int)N, (int)C, (int)Kw);
+    APTAI_CHECK_LAUNCH("conv_weight_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_posconv_weight(const float* v, const float* gain, float* norm_ws, void* w_fwd, void* w_dgrad,
+                                    int64_t H, int64_t groups, int64_t Kw, void* stream) {
+    APTAI_REQUIRE(v && gain && norm_ws && w_fwd, "aptai_posconv_weight: null pointer");
+    APTAI_REQUIRE(groups > 0 && H % groups == 0 && (H / groups) % 8 == 0, "aptai_posconv_weight: H=%ld groups=%ld", (long)H, (long)groups);
+    const int Cg = (int)(H / groups);
+    hipLaunchKernelGGL(posconv_norm_kernel, dim3((unsigned)Kw), dim3(256), 0, (hipStream_t)stream, v, norm_ws, (long)H * Cg, (int)Kw);
+    APTAI_CHECK_LAUNCH("posconv_norm_kernel");
+    hipLaunchKernelGGL(posconv_weight_kernel, dim3(grid_for(H * Cg * Kw)), dim3(256), 0, (hipStream_t)stream, v, gain,
+                       (const float*)norm_ws, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, (int)H, Cg, (int)Kw);
+    APTAI_CHECK_LAUNCH("posconv_weight_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_posconv_pack(const void* x, const void* u, void* xg, void* rowmajor_out, int64_t B, int64_t Tp,
+                                  int64_t H, int64_t groups, int64_t pad, void* stream) {
+    APTAI_REQUIRE(x && xg, "aptai_posconv_pack: null pointer");
+    APTAI_REQUIRE(groups > 0 && H % groups == 0 && (H / groups) % 4 == 0, "aptai_posconv_pack: H=%ld groups=%ld", (long)H, (long)groups);
+    hipLaunchKernelGGL(posconv_pack_kernel, dim3(grid_for(B * Tp * H / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)u, (bf16_t*)xg, (bf16_t*)rowmajor_out, (int)B, (int)Tp, (int)H,
+                       (int)(H / groups), (int)pad);
+    APTAI_CHECK_LAUNCH("posconv_pack_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_frame_mask_fwd(void* h, const int32_t* lens, const uint8_t* spec_mask, const float* embed, int64_t B,
+                                    int64_t Tp, int64_t T, int64_t H, void* stream) {
+    APTAI_REQUIRE(h && lens && H % 4 == 0, "aptai_frame_mask_fwd: bad arguments");
+    APTAI_REQUIRE(!spec_mask || embed, "aptai_frame_mask_fwd: spec mask without masked_spec_embed");
+    hipLaunchKernelGGL(frame_mask_kernel, dim3(grid_for(B * Tp * H / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)h, lens,
+                       spec_mask, embed, (int)B, (int)Tp, (int)T, (int)H);
+    APTAI_CHECK_LAUNCH("frame_mask_kernel");
+    return APTAI_OK;
+}
+
+static const int MASK_BWD_RPB = 32;
+extern "C" int64_t aptai_frame_mask_bwd_workspace_bytes(int64_t B, int64_t Tp, int64_t H) {
+    return ceil_div(B * Tp, MASK_BWD_RPB) * H * 4;
+}
+extern "C" int aptai_frame_mask_bwd(void* dy, const int32_t* lens, const uint8_t* spec_mask, float* dembed, void* workspace,
+                                    int64_t B, int64_t Tp, int64_t T, int64_t H, void* stream) {
+    APTAI_REQUIRE(dy && lens && H % 4 == 0, "aptai_frame_mask_bwd: bad arguments");
+    const long blocks = ceil_div(B * Tp, MASK_BWD_RPB);
+    const bool want = spec_mask && dembed;
+    APTAI_REQUIRE(!want || workspace, "aptai_frame_mask_bwd: workspace needed for dembed");
+    hipLaunchKernelGGL(frame_mask_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dy, lens,
+                       spec_mask, want ? (float*)workspace : nullptr, (int)B, (int)Tp, (int)T, (int)H, MASK_BWD_RPB);
+    APTAI_CHECK_LAUNCH("frame_mask_bwd_kernel");
+    if (want) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(H, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)workspace, dembed, (int)blocks, (int)H, 0);
+        APTAI_CHECK_LAUNCH("reduce_partials_kernel");
+    }
+    return APTAI_OK;
+}
+
+static const int COLSUM_RPB = 64;
+extern "C" int64_t aptai_colsum_workspace_bytes(int64_t rows, int64_t N) { return ceil_div(rows, COLSUM_RPB) * N * 4; }
+extern "C" int aptai_colsum_bf16(const void* x, int64_t ld, float* out, void* workspace, int64_t rows, int64_t N,
+                                 int accumulate, void* stream) {
+    APTAI_REQUIRE(x && out && workspace && rows > 0 && N % 4 == 0 && ld % 4 == 0, "aptai_colsum_bf16: bad arguments");
+    const long blocks = ceil_div(rows, COLSUM_RPB);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ld,
+                       (float*)workspace, (long)rows, (int)N, COLSUM_RPB);
+    APTAI_CHECK_LAUNCH("colsum_bf16_kernel");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, out, (int)blocks, (int)N, accumulate);
+    APTAI_CHECK_LAUNCH("reduce_partials_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_head_act_fwd(const void* h, void* a_tv, void* a_ph, int64_t n, float p_tv, float p_ph, uint64_t seed,
+                                  void* stream) {
+    APTAI_REQUIRE(h && a_tv && a_ph && n > 0, "aptai_head_act_fwd: bad arguments");
+    const uint32_t t1 = drop_thr16(p_tv), t2 = drop_thr16(p_ph);
+    hipLaunchKernelGGL(head_act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+                       (bf16_t*)a_tv, (bf16_t*)a_ph, (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t1, t2, drop_scale(t1),
+                       drop_scale(t2));
+    APTAI_CHECK_LAUNCH("head_act_fwd_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_head_act_bwd(const void* h, const void* d_tv, const void* d_ph, void* dh, int64_t n, float p_tv,
+                                  float p_ph, uint64_t seed, void* stream) {
+    APTAI_REQUIRE(h && d_tv && d_ph && dh && n > 0, "aptai_head_act_bwd: bad arguments");
+    const uint32_t t1 = drop_thr16(p_tv), t2 = drop_thr16(p_ph);
+    hipLaunchKernelGGL(head_act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+                       (const bf16_t*)d_tv, (const bf16_t*)d_ph, (bf16_t*)dh, (long)n, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       t1, t2, drop_scale(t1), drop_scale(t2));
+    APTAI_CHECK_LAUNCH("head_act_bwd_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream) {
+    APTAI_REQUIRE(x && y && n > 0, "aptai_dropout_bf16: bad arguments");
+    const uint32_t t = drop_thr16(p);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
+                       (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t, drop_scale(t));
+    APTAI_CHECK_LAUNCH("dropout_kernel");
+    return APTAI_OK;
+}

@@ -38,6 +38,9 @@ struct GemmArgs {
     int ktiles_per_split;
     long slab_stride;           // elements between split-K slabs (fp32 out only)
     int tiles_m, tiles_n;
+    // 2-level batching: blockIdx.y = outer * nb_inner + inner; element offsets per level
+    int nb_inner;
+    long sA[2], sB[2], sC[2], sBias[2], sR[2], sAux[2];
 };
 
 __device__ __forceinline__ int km_swz(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
@@ -106,6 +109,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
     const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+    if (gridDim.y > 1) {
+        const int bo = blockIdx.y / g.nb_inner, bi = blockIdx.y % g.nb_inner;
+        g.A += bo * g.sA[0] + bi * g.sA[1];
+        g.B += bo * g.sB[0] + bi * g.sB[1];
+        const long co = bo * g.sC[0] + bi * g.sC[1];
+        g.C = OUT_F32 ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
+        if (g.out_pre) g.out_pre += co;
+        if (g.bias) g.bias += bo * g.sBias[0] + bi * g.sBias[1];
+        if (g.residual) g.residual += bo * g.sR[0] + bi * g.sR[1];
+        if (g.aux) g.aux += bo * g.sAux[0] + bi * g.sAux[1];
+    }
     const int split = blockIdx.z;
     const int total_kt = g.K / BK;
     const int kt_begin = split * g.ktiles_per_split;
@@ -168,6 +182,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
                 }
+                if (flags & APTAI_EPI_BIAS) {
+                    const f32x4 b = *(const f32x4*)(g.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += b[r];
+                }
                 *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
             } else {
                 if (flags & APTAI_EPI_ALPHA) {
@@ -221,14 +240,14 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __r
 }
 
 template <bool A_KM, bool B_KM, bool OUT_F32>
-int launch_gemm(const GemmArgs& g, int nsplit, hipStream_t stream) {
+int launch_gemm(const GemmArgs& g, int nbatch, int nsplit, hipStream_t stream) {
     auto kern = gemm_kernel<A_KM, B_KM, OUT_F32>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
         attr_set = true;
     }
-    dim3 grid(g.tiles_m * g.tiles_n, 1, nsplit);
+    dim3 grid(g.tiles_m * g.tiles_n, nbatch, nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), 2 * STAGE_BYTES, stream, g);
     APTAI_CHECK_LAUNCH("gemm_kernel");
     return APTAI_OK;
@@ -277,7 +296,23 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     g.ktiles_per_split = (int)ceil_div(total_kt, nsplit);
     nsplit = (int)ceil_div(total_kt, g.ktiles_per_split);
 
+    int nbatch = 1;
+    g.nb_inner = 1;
+    if (d->batch_outer > 1 || d->batch_inner > 1) {
+        const int bo = d->batch_outer > 0 ? d->batch_outer : 1, bi = d->batch_inner > 0 ? d->batch_inner : 1;
+        nbatch = bo * bi;
+        g.nb_inner = bi;
+        for (int l = 0; l < 2; ++l) {
+            g.sA[l] = d->batch_stride_a[l]; g.sB[l] = d->batch_stride_b[l]; g.sC[l] = d->batch_stride_c[l];
+            g.sBias[l] = d->batch_stride_bias[l]; g.sR[l] = d->batch_stride_res[l]; g.sAux[l] = d->batch_stride_aux[l];
+            APTAI_REQUIRE(g.sA[l] % 8 == 0 && g.sB[l] % 8 == 0 && g.sC[l] % 4 == 0 && g.sBias[l] % 4 == 0 &&
+                              g.sR[l] % 4 == 0 && g.sAux[l] % 4 == 0,
+                          "aptai_gemm_bf16: batch strides must keep vector alignment");
+        }
+        APTAI_REQUIRE(nbatch <= 65535, "aptai_gemm_bf16: too many batches");
+    }
     const bool f32 = d->out_f32 != 0;
+    if (nbatch > 1) APTAI_REQUIRE(!(f32 && (d->split_k > 1 || d->accumulate)), "aptai_gemm_bf16: batched GEMM cannot split-K/accumulate");
     if (!f32) APTAI_REQUIRE(nsplit == 1, "aptai_gemm_bf16: split-K needs fp32 output");
     float* final_out = (float*)d->C;
     if (f32 && (nsplit > 1 || d->accumulate)) {
@@ -288,9 +323,9 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         g.slab_stride = (long)d->M * d->N;
     }
     int rc;
-    if (!d->a_kmajor && !d->b_kmajor) rc = f32 ? launch_gemm<false, false, true>(g, nsplit, stream) : launch_gemm<false, false, false>(g, nsplit, stream);
-    else if (!d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm<false, true, true>(g, nsplit, stream) : launch_gemm<false, true, false>(g, nsplit, stream);
-    else if (d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm<true, true, true>(g, nsplit, stream) : launch_gemm<true, true, false>(g, nsplit, stream);
+    if (!d->a_kmajor && !d->b_kmajor) rc = f32 ? launch_gemm<false, false, true>(g, nbatch, nsplit, stream) : launch_gemm<false, false, false>(g, nbatch, nsplit, stream);
+    else if (!d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm<false, true, true>(g, nbatch, nsplit, stream) : launch_gemm<false, true, false>(g, nbatch, nsplit, stream);
+    else if (d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm<true, true, true>(g, nbatch, nsplit, stream) : launch_gemm<true, true, false>(g, nbatch, nsplit, stream);
     else APTAI_FAIL(APTAI_ERR_INVALID, "aptai_gemm_bf16: A K-major with B K-contiguous is not built");
     if (rc != APTAI_OK) return rc;
     if (f32 && (nsplit > 1 || d->accumulate)) {

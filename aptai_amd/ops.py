@@ -23,7 +23,10 @@ class GemmDesc(ctypes.Structure):
                 ("a_kmajor", c_int), ("b_kmajor", c_int), ("out_f32", c_int), ("flags", c_int),
                 ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_i64), ("out_pre", c_void_p),
                 ("aux", c_void_p), ("ldaux", c_i64), ("alpha", c_float), ("dropout_p", c_float), ("seed", c_u64),
-                ("split_k", c_int), ("accumulate", c_int), ("workspace", c_void_p), ("workspace_bytes", c_i64)]
+                ("split_k", c_int), ("accumulate", c_int), ("workspace", c_void_p), ("workspace_bytes", c_i64),
+                ("batch_outer", c_int), ("batch_inner", c_int),
+                ("batch_stride_a", c_i64 * 2), ("batch_stride_b", c_i64 * 2), ("batch_stride_c", c_i64 * 2),
+                ("batch_stride_bias", c_i64 * 2), ("batch_stride_res", c_i64 * 2), ("batch_stride_aux", c_i64 * 2)]
 
 
 def _stream() -> int:
@@ -43,7 +46,7 @@ def _dev(*ts) -> None:
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, ldb=None, out=None, ldc=None,
          a_kmajor=False, b_kmajor=False, out_f32=False, bias=None, gelu=False, residual=None, out_pre=None,
          dgelu_aux=None, alpha: Optional[float] = None, dropout_p: float = 0.0, seed: int = 0, split_k: int = 1,
-         accumulate: bool = False, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+         accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None) -> torch.Tensor:
     """C[M,N] = rowop(A)[M,K] . colop(B)[N,K]^T.  See aptai_gemm_bf16 in include/aptai_hip.h."""
     _dev(a, b, out, bias, residual, out_pre, dgelu_aux)
     if out is None:
@@ -76,6 +79,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
         d.dropout_p, d.seed = dropout_p, seed
     d.flags = flags
     d.split_k, d.accumulate = split_k, int(accumulate)
+    if ldr is not None:
+        d.ldr = ldr
+    if batch is not None:
+        # batch = dict(outer=, inner=, a=(so,si), b=(so,si), c=(so,si), bias=(so,si), res=(so,si), aux=(so,si))
+        d.batch_outer, d.batch_inner = batch.get("outer", 1), batch.get("inner", 1)
+        for key, field in (("a", "batch_stride_a"), ("b", "batch_stride_b"), ("c", "batch_stride_c"),
+                           ("bias", "batch_stride_bias"), ("res", "batch_stride_res"), ("aux", "batch_stride_aux")):
+            so, si = batch.get(key, (0, 0))
+            getattr(d, field)[0], getattr(d, field)[1] = so, si
     if out_f32 and (split_k > 1 or accumulate):
         need = _lib.lib().aptai_gemm_workspace_bytes(M, N, split_k)
         if workspace is None or workspace.numel() * workspace.element_size() < need:
@@ -86,6 +98,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
 
 
 # ----------------------------------------------------------------------------- LayerNorm
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), device=device, dtype=torch.uint8)
+
+
 def layernorm_fwd(x, gamma, beta, eps, *, gelu_after=False, save_stats=True, out=None):
     _dev(x, gamma, beta)
     rows, cols = x.shape[0], x.shape[1]
@@ -94,10 +110,8 @@ def layernorm_fwd(x, gamma, beta, eps, *, gelu_after=False, save_stats=True, out
     if save_stats:
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-    _lib.check(_lib.lib().aptai_layernorm_fwd(c_void_p(x.data_ptr()), c_void_p(gamma.data_ptr()),
-                                              c_void_p(beta.data_ptr()), c_void_p(y.data_ptr()), c_void_p(_ptr(mean)),
-                                              c_void_p(_ptr(rstd)), c_i64(rows), c_i64(cols), c_float(eps),
-                                              c_int(int(gelu_after)), c_void_p(_stream())), "aptai_layernorm_fwd")
+    _lib.call("aptai_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _ptr(mean), _ptr(rstd),
+              rows, cols, eps, int(gelu_after), _stream())
     return y, mean, rstd
 
 
@@ -111,13 +125,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dres=None, dropout_p=0.0, seed=0,
     if need_param_grads:
         dgamma = torch.empty(cols, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(cols, device=x.device, dtype=torch.float32)
-    ws = torch.empty(_lib.lib().aptai_layernorm_bwd_workspace_bytes(c_i64(rows), c_i64(cols)), device=x.device,
-                     dtype=torch.uint8)
-    _lib.check(_lib.lib().aptai_layernorm_bwd(
-        c_void_p(dy.data_ptr()), c_void_p(x.data_ptr()), c_void_p(mean.data_ptr()), c_void_p(rstd.data_ptr()),
-        c_void_p(gamma.data_ptr()), c_void_p(_ptr(dres)), c_void_p(dx.data_ptr()), c_void_p(_ptr(dx_drop)),
-        c_float(dropout_p), c_u64(seed), c_void_p(_ptr(dgamma)), c_void_p(_ptr(dbeta)), c_void_p(ws.data_ptr()),
-        c_i64(rows), c_i64(cols), c_void_p(_stream())), "aptai_layernorm_bwd")
+    ws = _ws(_lib.lib().aptai_layernorm_bwd_workspace_bytes(rows, cols), x.device)
+    _lib.call("aptai_layernorm_bwd", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+              _ptr(dres), dx.data_ptr(), _ptr(dx_drop), dropout_p, seed, _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), rows,
+              cols, _stream())
     return dx, dx_drop, dgamma, dbeta
 
 
@@ -126,10 +137,8 @@ def attention_fwd(qkv, lens_i32, B, Tp, H, heads, *, dropout_p=0.0, seed=0, save
     _dev(qkv, lens_i32)
     ctx = torch.empty((B * Tp, H), device=qkv.device, dtype=torch.bfloat16)
     lse2 = torch.empty((B, heads, Tp), device=qkv.device, dtype=torch.float32) if save_lse else None
-    _lib.check(_lib.lib().aptai_attention_fwd(
-        c_void_p(qkv.data_ptr()), c_void_p(lens_i32.data_ptr()), c_void_p(ctx.data_ptr()), c_void_p(_ptr(lse2)),
-        c_i64(B), c_i64(Tp), c_i64(H), c_i64(heads), c_float((H // heads) ** -0.5), c_float(dropout_p), c_u64(seed),
-        c_void_p(_stream())), "aptai_attention_fwd")
+    _lib.call("aptai_attention_fwd", qkv.data_ptr(), lens_i32.data_ptr(), ctx.data_ptr(), _ptr(lse2), B, Tp, H, heads,
+              (H // heads) ** -0.5, dropout_p, seed, _stream())
     return ctx, lse2
 
 
@@ -137,9 +146,131 @@ def attention_bwd(qkv, lens_i32, ctx, dctx, lse2, B, Tp, H, heads, *, dropout_p=
     _dev(qkv, lens_i32, ctx, dctx, lse2)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, heads, Tp), device=qkv.device, dtype=torch.float32)
-    _lib.check(_lib.lib().aptai_attention_bwd(
-        c_void_p(qkv.data_ptr()), c_void_p(lens_i32.data_ptr()), c_void_p(ctx.data_ptr()), c_void_p(dctx.data_ptr()),
-        c_void_p(lse2.data_ptr()), c_void_p(delta.data_ptr()), c_void_p(dqkv.data_ptr()), c_i64(B), c_i64(Tp),
-        c_i64(H), c_i64(heads), c_float((H // heads) ** -0.5), c_float(dropout_p), c_u64(seed),
-        c_int(int(dctx_zero_beyond_len)), c_void_p(_stream())), "aptai_attention_bwd")
+    _lib.call("aptai_attention_bwd", qkv.data_ptr(), lens_i32.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse2.data_ptr(),
+              delta.data_ptr(), dqkv.data_ptr(), B, Tp, H, heads, (H // heads) ** -0.5, dropout_p, seed,
+              int(dctx_zero_beyond_len), _stream())
     return dqkv
+
+
+# ----------------------------------------------------------------------------- parameter prep
+def cast_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None, ld_dst: Optional[int] = None) -> torch.Tensor:
+    """fp32 [rows][cols] -> bf16 (optionally into a row slice of a wider buffer)."""
+    _dev(src, dst)
+    src2 = src.reshape(src.shape[0], -1) if src.dim() > 1 else src.reshape(1, -1)
+    rows, cols = src2.shape
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=torch.bfloat16)
+    _lib.call("aptai_cast_f32_to_bf16", src2.data_ptr(), dst.data_ptr(), rows, cols, ld_dst if ld_dst else cols, _stream())
+    return dst
+
+
+def conv_weight_bf16(w: torch.Tensor) -> torch.Tensor:
+    """[N][C][Kw] fp32 -> [N][Kw*C] bf16."""
+    _dev(w)
+    N, C, Kw = w.shape
+    out = torch.empty((N, Kw * C), device=w.device, dtype=torch.bfloat16)
+    _lib.call("aptai_conv_weight_to_bf16", w.data_ptr(), out.data_ptr(), N, C, Kw, _stream())
+    return out
+
+
+def posconv_weight(v, gain, groups, want_dgrad=True):
+    _dev(v, gain)
+    H, Cg, Kw = v.shape
+    norm = torch.empty(Kw, device=v.device, dtype=torch.float32)
+    wf = torch.empty((groups, Cg, Kw * Cg), device=v.device, dtype=torch.bfloat16)
+    wd = torch.empty_like(wf) if want_dgrad else None
+    _lib.call("aptai_posconv_weight", v.data_ptr(), gain.data_ptr(), norm.data_ptr(), wf.data_ptr(), _ptr(wd), H, groups, Kw,
+              _stream())
+    return wf, wd, norm
+
+
+def posconv_pack(x, xg, B, Tp, H, groups, pad, *, u=None, rowmajor_out=None):
+    _dev(x, xg, u, rowmajor_out)
+    _lib.call("aptai_posconv_pack", x.data_ptr(), _ptr(u), xg.data_ptr(), _ptr(rowmajor_out), B, Tp, H, groups, pad, _stream())
+
+
+def frame_mask_fwd(h, lens_i32, spec_mask_u8, embed, B, Tp, T, H):
+    _dev(h, lens_i32, spec_mask_u8, embed)
+    _lib.call("aptai_frame_mask_fwd", h.data_ptr(), lens_i32.data_ptr(), _ptr(spec_mask_u8), _ptr(embed), B, Tp, T, H, _stream())
+
+
+def frame_mask_bwd(dy, lens_i32, spec_mask_u8, B, Tp, T, H, want_dembed):
+    _dev(dy, lens_i32, spec_mask_u8)
+    dembed = ws = None
+    if want_dembed and spec_mask_u8 is not None:
+        dembed = torch.empty(H, device=dy.device, dtype=torch.float32)
+        ws = _ws(_lib.lib().aptai_frame_mask_bwd_workspace_bytes(B, Tp, H), dy.device)
+    _lib.call("aptai_frame_mask_bwd", dy.data_ptr(), lens_i32.data_ptr(), _ptr(spec_mask_u8), _ptr(dembed), _ptr(ws), B, Tp, T, H,
+              _stream())
+    return dembed
+
+
+def colsum(x, rows, N, *, ld=None, out=None, accumulate=False):
+    _dev(x, out)
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+    ws = _ws(_lib.lib().aptai_colsum_workspace_bytes(rows, N), x.device)
+    _lib.call("aptai_colsum_bf16", x.data_ptr(), ld if ld else x.stride(0), out.data_ptr(), ws.data_ptr(), rows, N,
+              int(accumulate), _stream())
+    return out
+
+
+def dropout(x, p, seed):
+    _dev(x)
+    y = torch.empty_like(x)
+    _lib.call("aptai_dropout_bf16", x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _stream())
+    return y
+
+
+# ----------------------------------------------------------------------------- conv layer 0
+def conv0_fwd(audio, weight, bias, gamma, beta, mode, out, T_real, T_alloc, eps=1e-5):
+    _dev(audio, weight, bias, gamma, beta, out)
+    B, S = audio.shape
+    C, _, Kw = weight.shape
+    ws = _ws(_lib.lib().aptai_conv0_workspace_bytes(B, T_real), audio.device) if mode == 0 else None
+    _lib.call("aptai_conv0_fwd", audio.data_ptr(), B, S, weight.data_ptr(), _ptr(bias), gamma.data_ptr(), beta.data_ptr(), mode,
+              eps, out.data_ptr(), T_real, T_alloc, C, Kw, 5, _ptr(ws), _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- APTAI heads
+def head_act_fwd(h, p_tv, p_ph, seed):
+    _dev(h)
+    a_tv, a_ph = torch.empty_like(h), torch.empty_like(h)
+    _lib.call("aptai_head_act_fwd", h.data_ptr(), a_tv.data_ptr(), a_ph.data_ptr(), h.numel(), p_tv, p_ph, seed, _stream())
+    return a_tv, a_ph
+
+
+def head_act_bwd(h, d_tv, d_ph, p_tv, p_ph, seed):
+    _dev(h, d_tv, d_ph)
+    dh = torch.empty_like(h)
+    _lib.call("aptai_head_act_bwd", h.data_ptr(), d_tv.data_ptr(), d_ph.data_ptr(), dh.data_ptr(), h.numel(), p_tv, p_ph, seed,
+              _stream())
+    return dh
+
+
+def lowpass_fir(x, ldx, rows_per_b_in, taps_f64, y, ldy, rows_per_b_out, B, T, T_out, C, C_out):
+    _dev(x, taps_f64, y)
+    _lib.call("aptai_lowpass_fir", x.data_ptr(), ldx, rows_per_b_in, taps_f64.data_ptr(), taps_f64.numel(), y.data_ptr(), ldy,
+              rows_per_b_out, int(y.dtype == torch.bfloat16), B, T, T_out, C, C_out, _stream())
+    return y
+
+
+def aptai_loss_fwd(tv_pred, tv_tgt, logits, ldl, rows_per_b, phn_tgt, B, T, n_tv, n_phn, w_mse, w_ce, want_pred=True):
+    _dev(tv_pred, tv_tgt, logits, phn_tgt)
+    scalars = torch.empty(5, device=tv_pred.device, dtype=torch.float32)
+    pred = torch.empty((B, T), device=tv_pred.device, dtype=torch.int64) if want_pred else None
+    ws = _ws(_lib.lib().aptai_aptai_loss_workspace_bytes(), tv_pred.device)
+    _lib.call("aptai_aptai_loss_fwd", tv_pred.data_ptr(), tv_tgt.data_ptr(), logits.data_ptr(), ldl, rows_per_b,
+              phn_tgt.data_ptr(), B, T, n_tv, n_phn, w_mse, w_ce, scalars.data_ptr(), _ptr(pred), ws.data_ptr(), _stream())
+    return scalars, pred
+
+
+def aptai_loss_bwd(tv_pred, tv_tgt, logits, ldl, rows_per_b, phn_tgt, B, T, n_tv, n_phn, w_mse, w_ce, scalars, grad_out, ldd=64):
+    _dev(tv_pred, tv_tgt, logits, phn_tgt, scalars, grad_out)
+    d_tv = torch.empty((B, T, n_tv), device=tv_pred.device, dtype=torch.float32)
+    d_logits = torch.empty((B * rows_per_b, ldd), device=tv_pred.device, dtype=torch.bfloat16)
+    _lib.call("aptai_aptai_loss_bwd", tv_pred.data_ptr(), tv_tgt.data_ptr(), logits.data_ptr(), ldl, rows_per_b,
+              phn_tgt.data_ptr(), B, T, n_tv, n_phn, w_mse, w_ce, scalars.data_ptr(), _ptr(grad_out), d_tv.data_ptr(),
+              d_logits.data_ptr(), ldd, _stream())
+    return d_tv, d_logits

@@ -1,0 +1,618 @@
+"""MI355X-native ``Wav2Vec2Model``: same module surface and state-dict keys as the HuggingFace class the
+reference instantiates (models/aptai.py:33-40, models/w2v2_pr.py:28-33), computed by hand-written HIP
+kernels (libaptai_hip.so) through ``aptai_amd.ops``.  No ``transformers`` import, no CPU fallback.
+
+Layout: activations are channels-last bf16 ``[B*Tp][C]`` with ``Tp`` = frames per utterance padded to a
+multiple of 128 (>= T+2); frames in [T, Tp) are treated exactly like the reference's padded frames (zeroed
+before the encoder, masked as attention keys, never touched by a loss), so they cannot influence valid
+frames.  Parameters stay fp32 ``nn.Parameter``s (drop-in for ``torch.optim.Adam`` and ``state_dict``); bf16
+compute copies are cached per parameter version.  "HF:n" cites modeling_wav2vec2.py (transformers 5.15.0).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from types import SimpleNamespace
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hostlogic, ops
+from .config import W2V2Config
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class _Holder(nn.Module):
+    """Parameter container (the arithmetic lives in the HIP kernels, not in module forwards)."""
+
+
+def _linear(out_f: int, in_f: int, std: float = 0.02) -> _Holder:
+    m = _Holder()
+    m.weight = nn.Parameter(torch.randn(out_f, in_f) * std)
+    m.bias = nn.Parameter(torch.zeros(out_f))
+    return m
+
+
+def _norm(c: int) -> _Holder:
+    m = _Holder()
+    m.weight = nn.Parameter(torch.ones(c))
+    m.bias = nn.Parameter(torch.zeros(c))
+    return m
+
+
+class Wav2Vec2BaseModelOutput(dict):
+    """Minimal stand-in for HF's ModelOutput: attribute, key and integer access (``outputs[0]``)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [v for v in self.values() if v is not None][k]
+        return dict.__getitem__(self, k)
+
+
+# =================================================================================== generic autograd glue
+class _OpFn(torch.autograd.Function):
+    """forward(impl, x, *params): impl.fwd(x, params) -> (outputs tuple, saved); backward -> impl.bwd(saved, grads)."""
+
+    @staticmethod
+    def forward(ctx, impl, need, x, *params):
+        outs, saved = impl.fwd(x, params, need)          # grad mode is off in here: `need` is decided by the caller
+        ctx.impl, ctx.saved = impl, saved
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        dx, pgrads = ctx.impl.bwd(ctx.saved, grads, ctx.needs_input_grad[2])
+        ctx.saved = None
+        return (None, None, dx) + tuple(pgrads)
+
+
+def _run(impl, x, *params):
+    need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params if p is not None))
+    return _OpFn.apply(impl, need, x, *params)
+
+
+def _seed(base: int, *ids: int) -> int:
+    s = base & 0xFFFFFFFFFFFF
+    for i in ids:
+        s = (s * 1000003 + i + 1) & 0xFFFFFFFFFFFFFFFF
+    return s
+
+
+# =================================================================================== encoder layer
+class _LayerImpl:
+    """One transformer layer (HF:575-654).  post-LN (base) or pre-LN (do_stable_layer_norm, large)."""
+
+    def __init__(self, cfg: W2V2Config, geom, lens_i32, w, training: bool, seed: int):
+        self.cfg, self.g, self.lens, self.w, self.training, self.seed = cfg, geom, lens_i32, w, training, seed
+
+    # params: ln1.w ln1.b ln2.w ln2.b, then the 12 fp32 linear parameters (q,k,v weights; q,k,v biases; out w,b;
+    # ffn1 w,b; ffn2 w,b).  The forward reads their cached bf16 copies in `w`; the backward returns their gradients.
+    def fwd(self, x, params, need):
+        cfg, g, w = self.cfg, self.g, self.w
+        M, H, I = g.M, cfg.hidden_size, cfg.intermediate_size
+        ln1w, ln1b, ln2w, ln2b = params[0], params[1], params[2], params[3]
+        tr = self.training
+        p_h = cfg.hidden_dropout if tr else 0.0
+        p_a = cfg.activation_dropout if tr else 0.0
+        p_att = cfg.attention_dropout if tr else 0.0
+        s = SimpleNamespace(x=x)
+        pre = cfg.do_stable_layer_norm
+        if pre:
+            n1, s.m1, s.r1 = ops.layernorm_fwd(x, ln1w, ln1b, cfg.layer_norm_eps, save_stats=need)
+            attn_in = n1
+            s.n1 = n1
+        else:
+            attn_in = x
+        s.qkv = ops.gemm(attn_in, w.wqkv, M, 3 * H, H, bias=w.bqkv)
+        s.ctx, s.lse = ops.attention_fwd(s.qkv, self.lens, g.B, g.Tp, H, cfg.num_attention_heads, dropout_p=p_att,
+                                         seed=_seed(self.seed, 1), save_lse=need)
+        s.s1 = ops.gemm(s.ctx, w.wo, M, H, H, bias=w.bo, residual=x, dropout_p=p_h, seed=_seed(self.seed, 2))
+        if pre:
+            ffn_in, s.m2, s.r2 = ops.layernorm_fwd(s.s1, ln2w, ln2b, cfg.layer_norm_eps, save_stats=need)
+            s.n2 = ffn_in
+        else:
+            ffn_in, s.m1, s.r1 = ops.layernorm_fwd(s.s1, ln1w, ln1b, cfg.layer_norm_eps, save_stats=need)
+            s.x1 = ffn_in
+        s.u = torch.empty((M, I), device=x.device, dtype=torch.bfloat16) if need else None
+        s.hact = ops.gemm(ffn_in, w.w1, M, I, H, bias=w.b1, gelu=True, out_pre=s.u, dropout_p=p_a, seed=_seed(self.seed, 3))
+        res2 = s.s1 if pre else ffn_in
+        s.s2 = ops.gemm(s.hact, w.w2, M, H, I, bias=w.b2, residual=res2, dropout_p=p_h, seed=_seed(self.seed, 4))
+        if pre:
+            y = s.s2
+        else:
+            y, s.m2, s.r2 = ops.layernorm_fwd(s.s2, ln2w, ln2b, cfg.layer_norm_eps, save_stats=need)
+        s.p = (p_h, p_a, p_att)
+        s.ln = (ln1w, ln1b, ln2w, ln2b)
+        return (y,), (s if need else None)
+
+    def bwd(self, s, grads, x_needs):
+        cfg, g, w = self.cfg, self.g, self.w
+        M, H, I = g.M, cfg.hidden_size, cfg.intermediate_size
+        heads = cfg.num_attention_heads
+        p_h, p_a, p_att = s.p
+        ln1w, ln1b, ln2w, ln2b = s.ln
+        dy = grads[0].contiguous()
+        pre = cfg.do_stable_layer_norm
+        sk = w.split_k
+        # ---- FFN block
+        if pre:
+            ds2 = dy                                             # y = s1 + D(ffn)
+            d_ffn_out = ops.dropout(ds2, p_h, _seed(self.seed, 4)) if p_h > 0 else ds2
+            ffn_in = s.n2
+        else:
+            ds2, d_ffn_out, dg2, db2 = ops.layernorm_bwd(dy, s.s2, s.m2, s.r2, ln2w, dropout_p=p_h, seed=_seed(self.seed, 4))
+            if d_ffn_out is None:
+                d_ffn_out = ds2
+            ffn_in = s.x1
+        dw2 = ops.gemm(d_ffn_out, s.hact, H, I, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[3])
+        dbias2 = ops.colsum(d_ffn_out, M, H)
+        du = ops.gemm(d_ffn_out, w.w2, M, I, H, b_kmajor=True, dgelu_aux=s.u, dropout_p=p_a, seed=_seed(self.seed, 3))
+        dw1 = ops.gemm(du, ffn_in, I, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[2])
+        dbias1 = ops.colsum(du, M, I)
+        if pre:
+            dn2 = ops.gemm(du, w.w1, M, H, I, b_kmajor=True)
+            ds1, d_att_out, dg2, db2 = ops.layernorm_bwd(dn2, s.s1, s.m2, s.r2, ln2w, dres=ds2, dropout_p=p_h,
+                                                         seed=_seed(self.seed, 2))
+        else:
+            dx1 = ops.gemm(du, w.w1, M, H, I, b_kmajor=True, residual=ds2)
+            ds1, d_att_out, dg1, db1 = ops.layernorm_bwd(dx1, s.s1, s.m1, s.r1, ln1w, dropout_p=p_h, seed=_seed(self.seed, 2))
+        if d_att_out is None:
+            d_att_out = ds1
+        # ---- attention block
+        dwo = ops.gemm(d_att_out, s.ctx, H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[1])
+        dbo = ops.colsum(d_att_out, M, H)
+        dctx = ops.gemm(d_att_out, w.wo, M, H, H, b_kmajor=True)
+        dqkv = ops.attention_bwd(s.qkv, self.lens, s.ctx, dctx, s.lse, g.B, g.Tp, H, heads, dropout_p=p_att,
+                                 seed=_seed(self.seed, 1), dctx_zero_beyond_len=True)
+        attn_in = s.n1 if pre else s.x
+        dwqkv = ops.gemm(dqkv, attn_in, 3 * H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[0])
+        dbqkv = ops.colsum(dqkv, M, 3 * H)
+        if pre:
+            dn1 = ops.gemm(dqkv, w.wqkv, M, H, 3 * H, b_kmajor=True)
+            dx, _, dg1, db1 = ops.layernorm_bwd(dn1, s.x, s.m1, s.r1, ln1w, dres=ds1)
+        else:
+            dx = ops.gemm(dqkv, w.wqkv, M, H, 3 * H, b_kmajor=True, residual=ds1)
+        return dx, (dg1, db1, dg2, db2, dwqkv[0:H], dwqkv[H:2 * H], dwqkv[2 * H:3 * H], dbqkv[0:H], dbqkv[H:2 * H],
+                    dbqkv[2 * H:3 * H], dwo, dbo, dw1, dbias1, dw2, dbias2)
+
+
+# =================================================================================== front end of the encoder
+class _FrontImpl:
+    """Feature projection (HF:422-434) -> SpecAugment fill + padded-frame zeroing (HF:1292-1295, 678-681) ->
+    h + GELU(grouped positional conv(h)) (HF:326-379, 689-692) -> [LayerNorm for post-LN models] -> dropout."""
+
+    def __init__(self, cfg, geom, lens_i32, spec, training, seed, model):
+        self.cfg, self.g, self.lens, self.spec, self.training, self.seed, self.model = cfg, geom, lens_i32, spec, training, seed, model
+
+    def _packed(self, key, dev):
+        cfg, g = self.cfg, self.g
+        Cg = cfg.hidden_size // cfg.num_conv_pos_embedding_groups
+        pad = cfg.num_conv_pos_embeddings // 2
+        rows_p = g.Tp + 2 * pad
+        n = cfg.num_conv_pos_embedding_groups * g.B * rows_p * Cg + Cg * 8
+        buf = self.model._scratch(key, n, dev)
+        return buf, rows_p, Cg, pad
+
+    def _posconv_batch(self, Cg, rows_p, K, a_off=0):
+        cfg, g = self.cfg, self.g
+        G = cfg.num_conv_pos_embedding_groups
+        H = cfg.hidden_size
+        return dict(outer=g.B, inner=G, a=(rows_p * Cg, g.B * rows_p * Cg), b=(0, Cg * K), c=(g.Tp * H, Cg),
+                    bias=(0, Cg), res=(g.Tp * H, Cg), aux=(g.Tp * H, Cg))
+
+    def fwd(self, feats, params, need):
+        cfg, g = self.cfg, self.g
+        (fplw, fplb, pw, pb, embed, pcg, pcv, pcb, elw, elb) = params
+        M, H, C = g.M, cfg.hidden_size, feats.shape[1]
+        tr = self.training
+        s = SimpleNamespace(feats=feats, params=params)
+        s.n0, s.m0, s.r0 = ops.layernorm_fwd(feats, fplw, fplb, cfg.layer_norm_eps, save_stats=need)
+        wp = self.model._cached(("proj",), [pw], lambda: ops.cast_bf16(pw))
+        s.p_fp = cfg.feat_proj_dropout if tr else 0.0
+        h0 = ops.gemm(s.n0, wp, M, H, C, bias=pb, dropout_p=s.p_fp, seed=_seed(self.seed, 11))
+        ops.frame_mask_fwd(h0, self.lens, self.spec, embed, g.B, g.Tp, g.T, H)
+        s.h0 = h0
+        # positional conv as ONE batched implicit GEMM over (utterance, group) on a zero-gapped group-major copy
+        G, Kw = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
+        xg, rows_p, Cg, pad = self._packed("pc_x", feats.device)
+        ops.posconv_pack(h0, xg, g.B, g.Tp, H, G, pad)
+        s.wf, s.wd, s.norm = self.model._cached(("posconv",), [pcg, pcv], lambda: ops.posconv_weight(pcv, pcg.reshape(-1), G))
+        K = Kw * Cg
+        s.u = torch.empty((M, H), device=feats.device, dtype=torch.bfloat16) if need else None
+        s.s = torch.empty((M, H), device=feats.device, dtype=torch.bfloat16)
+        ops.gemm(xg, s.wf, g.Tp, Cg, K, lda=Cg, ldb=K, out=s.s, ldc=H, bias=pcb, gelu=True, residual=h0, ldr=H, out_pre=s.u,
+                 batch=self._posconv_batch(Cg, rows_p, K))
+        s.xg_key = "pc_x"
+        self.model._scratch_owner["pc_x"] = s
+        if cfg.do_stable_layer_norm:
+            y = s.s
+        else:
+            y, s.m1, s.r1 = ops.layernorm_fwd(s.s, elw, elb, cfg.layer_norm_eps, save_stats=need)
+        s.p_h = cfg.hidden_dropout if tr else 0.0
+        if s.p_h > 0:
+            y = ops.dropout(y, s.p_h, _seed(self.seed, 12))
+        return (y,), (s if need else None)
+
+    def bwd(self, s, grads, x_needs):
+        cfg, g = self.cfg, self.g
+        (fplw, fplb, pw, pb, embed, pcg, pcv, pcb, elw, elb) = s.params
+        M, H, C = g.M, cfg.hidden_size, s.feats.shape[1]
+        G, Kw = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
+        dy = grads[0].contiguous()
+        if s.p_h > 0:
+            dy = ops.dropout(dy, s.p_h, _seed(self.seed, 12))
+        delw = delb = None
+        if cfg.do_stable_layer_norm:
+            ds = dy
+        else:
+            ds, _, delw, delb = ops.layernorm_bwd(dy, s.s, s.m1, s.r1, elw)
+        # ---- positional conv backward
+        dug, rows_p, Cg, pad = self._packed("pc_du", dy.device)
+        K = Kw * Cg
+        du_rm = torch.empty((M, H), device=dy.device, dtype=torch.bfloat16)
+        ops.posconv_pack(ds, dug, g.B, g.Tp, H, G, pad, u=s.u, rowmajor_out=du_rm)
+        dpcb = ops.colsum(du_rm, M, H)
+        dh0 = torch.empty((M, H), device=dy.device, dtype=torch.bfloat16)
+        ops.gemm(dug[Cg:], s.wd, g.Tp, Cg, K, lda=Cg, ldb=K, out=dh0, ldc=H, residual=ds, ldr=H,
+                 batch=self._posconv_batch(Cg, rows_p, K))
+        xg, _, _, _ = self._packed(s.xg_key, dy.device)
+        if self.model._scratch_owner.get(s.xg_key) is not s:
+            ops.posconv_pack(s.h0, xg, g.B, g.Tp, H, G, pad)         # another forward reused the scratch: repack
+        kred = g.B * rows_p - 2 * pad
+        dwf = torch.empty((G, Cg, K), device=dy.device, dtype=torch.float32)
+        ops.gemm(dug[pad * Cg:], xg, Cg, K, kred, a_kmajor=True, b_kmajor=True, out_f32=True, lda=Cg, ldb=Cg, out=dwf, ldc=K,
+                 batch=dict(outer=1, inner=G, a=(0, g.B * rows_p * Cg), b=(0, g.B * rows_p * Cg), c=(0, Cg * K)))
+        # weight-norm backward (parameter-sized fp32 math): w = g * v / ||v||
+        dW = dwf.view(G, Cg, Kw, Cg).permute(0, 1, 3, 2).reshape(H, Cg, Kw)
+        v = pcv.detach()
+        norm = s.norm.view(1, 1, Kw)
+        gain = pcg.detach().view(1, 1, Kw)
+        dot = (dW * v).sum(dim=(0, 1), keepdim=True)
+        dpcg = (dot / norm).reshape(pcg.shape)
+        dpcv = gain / norm * (dW - v * dot / (norm * norm))
+        # ---- mask + projection + LN
+        dembed = ops.frame_mask_bwd(dh0, self.lens, self.spec, g.B, g.Tp, g.T, H, want_dembed=embed is not None)
+        if s.p_fp > 0:
+            dh0 = ops.dropout(dh0, s.p_fp, _seed(self.seed, 11))
+        sk = max(1, min(8, M // 2048))
+        dpw = ops.gemm(dh0, s.n0, H, C, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk)
+        dpb = ops.colsum(dh0, M, H)
+        wp = self.model._cached(("proj",), [pw], lambda: ops.cast_bf16(pw))
+        dn0 = ops.gemm(dh0, wp, M, C, H, b_kmajor=True)
+        dfeats, _, dfplw, dfplb = ops.layernorm_bwd(dn0, s.feats, s.m0, s.r0, fplw)
+        return (dfeats if x_needs else None), (dfplw, dfplb, dpw, dpb, dembed, dpcg, dpcv, dpcb, delw, delb)
+
+
+class _FinalLNImpl:
+    """encoder.layer_norm after the last layer of pre-LN models (HF:791)."""
+
+    def __init__(self, cfg, geom):
+        self.cfg, self.g = cfg, geom
+
+    def fwd(self, x, params, need):
+        y, m, r = ops.layernorm_fwd(x, params[0], params[1], self.cfg.layer_norm_eps, save_stats=need)
+        return (y,), (SimpleNamespace(x=x, m=m, r=r, w=params[0]) if need else None)
+
+    def bwd(self, s, grads, x_needs):
+        dx, _, dg, db = ops.layernorm_bwd(grads[0].contiguous(), s.x, s.m, s.r, s.w)
+        return dx, (dg, db)
+
+
+# =================================================================================== the model
+class Wav2Vec2Model(nn.Module):
+    """Drop-in for ``transformers.Wav2Vec2Model`` on the reference's call pattern."""
+
+    def __init__(self, config):
+        super().__init__()
+        cfg = W2V2Config.from_any(config)
+        self.config = cfg
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        if cfg.head_dim != 64:
+            raise ValueError("the attention kernels are built for head_dim 64 (wav2vec2 base/large)")
+        if any(c != 512 for c in cfg.conv_dim) or cfg.conv_kernel[0] != 10 or cfg.conv_stride[0] != 5:
+            raise ValueError("the feature-encoder kernels are built for conv_dim=512, first layer k=10/s=5")
+        # ---- feature encoder (HF:382-419)
+        fe = _Holder()
+        layers = []
+        cin = 1
+        for i, (c, k) in enumerate(zip(cfg.conv_dim, cfg.conv_kernel)):
+            l = _Holder()
+            l.conv = _Holder()
+            w = torch.empty(c, cin, k)
+            nn.init.kaiming_normal_(w)
+            l.conv.weight = nn.Parameter(w)
+            if cfg.conv_bias:
+                bound = math.sqrt(1.0 / (cin * k))
+                l.conv.bias = nn.Parameter(torch.empty(c).uniform_(-bound, bound))
+            if cfg.feat_extract_norm == "layer" or i == 0:
+                l.layer_norm = _norm(c)
+            layers.append(l)
+            cin = c
+        fe.conv_layers = nn.ModuleList(layers)
+        self.feature_extractor = fe
+        self._fe_requires_grad = True
+        # ---- feature projection (HF:422-434)
+        fp = _Holder()
+        fp.layer_norm = _norm(cin)
+        fp.projection = _linear(H, cin)
+        self.feature_projection = fp
+        if cfg.mask_time_prob > 0.0 or cfg.mask_feature_prob > 0.0:
+            self.masked_spec_embed = nn.Parameter(torch.empty(H).uniform_())
+        # ---- encoder (HF:657-802)
+        enc = _Holder()
+        pc = _Holder()
+        pc.conv = _Holder()
+        k, grp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+        pc.conv.bias = nn.Parameter(torch.zeros(H))
+        pc.conv.parametrizations = _Holder()
+        pc.conv.parametrizations.weight = _Holder()
+        v = torch.randn(H, H // grp, k) * (2 * math.sqrt(1 / (k * H)))
+        pc.conv.parametrizations.weight.original0 = nn.Parameter(v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+        pc.conv.parametrizations.weight.original1 = nn.Parameter(v)
+        enc.pos_conv_embed = pc
+        enc.layer_norm = _norm(H)
+        ls = []
+        for _ in range(cfg.num_hidden_layers):
+            l = _Holder()
+            l.attention = _Holder()
+            for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                setattr(l.attention, n, _linear(H, H))
+            l.layer_norm = _norm(H)
+            l.feed_forward = _Holder()
+            l.feed_forward.intermediate_dense = _linear(I, H)
+            l.feed_forward.output_dense = _linear(H, I)
+            l.final_layer_norm = _norm(H)
+            ls.append(l)
+        enc.layers = nn.ModuleList(ls)
+        self.encoder = enc
+        self._cache = {}
+        self._scratch_bufs = {}
+        self._scratch_owner = {}
+        self._step = 0
+        self.base_seed = 0x5EED
+
+    # ------------------------------------------------------------------ reference-facing helpers
+    @classmethod
+    def from_pretrained(cls, model_id_or_path, config=None, cache_dir=None, **kw):
+        """Loads a LOCAL HuggingFace checkpoint directory (config.json + model.safetensors | pytorch_model.bin).
+        Hub names cannot be resolved offline and raise."""
+        path = str(model_id_or_path)
+        if not os.path.isdir(path):
+            raise FileNotFoundError(
+                f"{path!r} is not a local checkpoint directory; hub downloads are not available to this build")
+        cfg = W2V2Config.from_any(config) if config is not None else W2V2Config.from_pretrained_dir(path)
+        model = cls(cfg)
+        sd = None
+        st = os.path.join(path, "model.safetensors")
+        pb = os.path.join(path, "pytorch_model.bin")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        elif os.path.exists(pb):
+            sd = torch.load(pb, map_location="cpu", weights_only=True)
+        if sd is None:
+            raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
+        sd = {(k[len("wav2vec2."):] if k.startswith("wav2vec2.") else k): v for k, v in sd.items()}
+        own = model.state_dict()
+        # legacy weight-norm names (weight_g / weight_v) -> parametrizations
+        ren = {"encoder.pos_conv_embed.conv.weight_g": "encoder.pos_conv_embed.conv.parametrizations.weight.original0",
+               "encoder.pos_conv_embed.conv.weight_v": "encoder.pos_conv_embed.conv.parametrizations.weight.original1"}
+        sd = {ren.get(k, k): v for k, v in sd.items()}
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise KeyError(f"checkpoint {path} lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        model.load_state_dict({k: sd[k] for k in own})
+        return model
+
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.config.to_dict(), f, indent=1)
+        from safetensors.torch import save_file
+        save_file({k: v.contiguous() for k, v in self.state_dict().items()}, os.path.join(path, "model.safetensors"))
+
+    def gradient_checkpointing_enable(self, *a, **kw):
+        """Accepted for drop-in compatibility (models/aptai.py:38): 288 GB of HBM make recomputation unnecessary."""
+        return None
+
+    def freeze_feature_encoder(self):
+        """HF:1265-1270."""
+        for p in self.feature_extractor.parameters():
+            p.requires_grad = False
+        self._fe_requires_grad = False
+
+    def _get_feat_extract_output_lengths(self, input_lengths, add_adapter=None):
+        return hostlogic.feat_extract_output_lengths(input_lengths, self.config.conv_kernel, self.config.conv_stride)
+
+    # ------------------------------------------------------------------ bf16 compute copies of the parameters
+    def _versions(self, params):
+        return tuple((p.data_ptr(), p._version) for p in params)
+
+    def _cached(self, key, params, build):
+        ver = self._versions(params)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            val = build()
+        self._cache[key] = (ver, val)
+        return val
+
+    def _layer_weights(self, i: int, M: int):
+        l = self.encoder.layers[i]
+        at, ff = l.attention, l.feed_forward
+        params = [at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, at.q_proj.bias, at.k_proj.bias, at.v_proj.bias,
+                  at.out_proj.weight, at.out_proj.bias, ff.intermediate_dense.weight, ff.intermediate_dense.bias,
+                  ff.output_dense.weight, ff.output_dense.bias]
+        H, I = self.config.hidden_size, self.config.intermediate_size
+
+        def build():
+            dev = params[0].device
+            wqkv = torch.empty((3 * H, H), device=dev, dtype=torch.bfloat16)
+            for j in range(3):
+                ops.cast_bf16(params[j], wqkv[j * H:(j + 1) * H])
+            e = SimpleNamespace(wqkv=wqkv, bqkv=torch.cat([params[3], params[4], params[5]]).float().contiguous(),
+                                wo=ops.cast_bf16(params[6]), bo=params[7].detach().float(),
+                                w1=ops.cast_bf16(params[8]), b1=params[9].detach().float(),
+                                w2=ops.cast_bf16(params[10]), b2=params[11].detach().float())
+            return e
+        e = self._cached(("layer", i), params, build)
+        e.split_k = self._split_k(M)
+        return e, params
+
+    def _split_k(self, M: int):
+        """split-K factors for the four wgrad GEMMs (qkv, out, ffn1, ffn2): fill ~2 blocks per CU."""
+        H, I = self.config.hidden_size, self.config.intermediate_size
+
+        def pick(rows, cols):
+            tiles = ((rows + 127) // 128) * ((cols + 127) // 128)
+            s = max(1, min(16, 512 // max(tiles, 1)))
+            return max(1, min(s, M // 512 if M >= 512 else 1))
+        return (pick(3 * H, H), pick(H, H), pick(I, H), pick(H, I))
+
+    def _scratch(self, key, numel, dev):
+        """Persistent zero-initialised bf16 scratch (the zero gap rows of the packed positional-conv operands are
+        written once here and never again)."""
+        cur = self._scratch_bufs.get(key)
+        if cur is None or cur.numel() != numel or cur.device != dev:
+            cur = torch.zeros(numel, device=dev, dtype=torch.bfloat16)
+            self._scratch_bufs[key] = cur
+        return cur
+
+    # ------------------------------------------------------------------ geometry of one batch
+    def _geometry(self, B: int, S: int) -> SimpleNamespace:
+        cfg = self.config
+        Tl = hostlogic.conv_layer_lengths(S, cfg.conv_kernel, cfg.conv_stride)
+        T = Tl[-1]
+        if T < 1:
+            raise ValueError(f"input of {S} samples is shorter than the receptive field of the feature encoder")
+        Tp = _round_up(T + 2, 128)
+        alloc = [0] * len(Tl)
+        alloc[-1] = Tp
+        for i in range(len(Tl) - 2, -1, -1):
+            alloc[i] = alloc[i + 1] * cfg.conv_stride[i + 1]
+        return SimpleNamespace(B=B, S=S, T=T, Tp=Tp, M=B * Tp, Tl=Tl, alloc=alloc)
+
+    # ------------------------------------------------------------------ feature encoder (conv stack)
+    def _conv_weights(self):
+        cl = self.feature_extractor.conv_layers
+        params = [l.conv.weight for l in cl[1:]]
+        return self._cached(("convw",), params, lambda: [ops.conv_weight_bf16(p) for p in params])
+
+    def _feature_encoder(self, audio: torch.Tensor, g) -> torch.Tensor:
+        cfg = self.config
+        cl = self.feature_extractor.conv_layers
+        trainable = torch.is_grad_enabled() and any(p.requires_grad for p in self.feature_extractor.parameters())
+        if trainable:
+            raise NotImplementedError(
+                "backward through the conv feature encoder is not built yet: call freeze_feature_encoder() "
+                "(APTAI's default, models/aptai.py:24,39) or run under torch.no_grad()")
+        with torch.no_grad():
+            dev = audio.device
+            C = 512
+            layer_mode = cfg.feat_extract_norm == "layer"
+            buf = torch.zeros((g.B * g.alloc[0] + 8, C), device=dev, dtype=torch.bfloat16)
+            l0 = cl[0]
+            ops.conv0_fwd(audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight,
+                          l0.layer_norm.bias, 1 if layer_mode else 0, buf, g.Tl[0], g.alloc[0])
+            ws = self._conv_weights()
+            for i in range(1, len(cl)):
+                k, s = cfg.conv_kernel[i], cfg.conv_stride[i]
+                Mi = g.B * g.alloc[i]
+                out = torch.zeros((Mi + 8, C), device=dev, dtype=torch.bfloat16)
+                bias = cl[i].conv.bias if cfg.conv_bias else None
+                ops.gemm(buf, ws[i - 1], Mi, C, k * C, lda=s * C, out=out, ldc=C, bias=bias, gelu=not layer_mode)
+                if layer_mode:
+                    ops.layernorm_fwd(out[:Mi], cl[i].layer_norm.weight, cl[i].layer_norm.bias, 1e-5, gelu_after=True,
+                                      save_stats=False, out=out[:Mi])
+                buf = out
+            return buf[:g.M]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_values, attention_mask=None, mask_time_indices=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, **kw):
+        """HF:1319-1375.  ``attention_mask`` follows the reference's convention: the (B,1) tensor of sample
+        counts (models/aptai.py:77), or a regular (B,S) 0/1 mask; both reduce to lengths via a row sum (HF:1023)."""
+        cfg = self.config
+        if not input_values.is_cuda:
+            raise ops._lib.AptaiHipError("Wav2Vec2Model runs on the MI355X only (no CPU fallback)")
+        if output_attentions:
+            raise NotImplementedError("attention probabilities never leave the fused kernel")
+        audio = input_values.float().contiguous()
+        B, S = audio.shape
+        g = self._geometry(B, S)
+        dev = audio.device
+        if attention_mask is not None:
+            sample_lens = attention_mask.to(dev).long().sum(-1)
+            frame_lens = hostlogic.feat_extract_output_lengths(sample_lens, cfg.conv_kernel, cfg.conv_stride)
+            frame_lens = frame_lens.clamp(min=1, max=g.T)
+        else:
+            frame_lens = torch.full((B,), g.T, device=dev, dtype=torch.long)
+        lens_i32 = frame_lens.to(torch.int32).contiguous()
+        self._step += 1
+        seed = _seed(self.base_seed, self._step)
+        training = self.training
+
+        feats = self._feature_encoder(audio, g)                                         # [M][512] bf16
+        # ---- feature projection + SpecAugment + padded-frame zeroing (HF:429-434, 1272-1316, 678-681)
+        spec = None
+        if getattr(cfg, "apply_spec_augment", True):
+            if mask_time_indices is not None:
+                spec = torch.as_tensor(mask_time_indices).to(dev).to(torch.uint8).contiguous()
+            elif cfg.mask_time_prob > 0 and training:
+                am = None
+                if attention_mask is not None:
+                    am = (torch.arange(g.T)[None, :] < frame_lens.cpu()[:, None])
+                m = hostlogic.compute_mask_indices((B, g.T), cfg.mask_time_prob, cfg.mask_time_length, attention_mask=am,
+                                                   min_masks=cfg.mask_time_min_masks)
+                spec = torch.from_numpy(m.astype(np.uint8)).to(dev)
+        fp = self.feature_projection
+        embed = getattr(self, "masked_spec_embed", None)
+        front = _FrontImpl(cfg, g, lens_i32, spec, training, seed, self)
+        pc = self.encoder.pos_conv_embed.conv
+        fparams = [fp.layer_norm.weight, fp.layer_norm.bias, fp.projection.weight, fp.projection.bias,
+                   embed if (embed is not None and spec is not None) else None,
+                   pc.parametrizations.weight.original0, pc.parametrizations.weight.original1, pc.bias,
+                   self.encoder.layer_norm.weight, self.encoder.layer_norm.bias]
+        h = _run(front, feats, *fparams)
+        # ---- transformer layers with LayerDrop (HF:694-707 / 767-780)
+        hidden = []
+        for i, layer in enumerate(self.encoder.layers):
+            hidden.append(h)
+            skip = training and (float(torch.rand([])) < cfg.layerdrop)
+            if skip:
+                continue
+            w, lin_params = self._layer_weights(i, g.M)
+            impl = _LayerImpl(cfg, g, lens_i32, w, training, _seed(seed, 100 + i))
+            h = _run(impl, h, layer.layer_norm.weight, layer.layer_norm.bias, layer.final_layer_norm.weight,
+                            layer.final_layer_norm.bias, *lin_params)
+        if cfg.do_stable_layer_norm:
+            fin = _FinalLNImpl(cfg, g)
+            h = _run(fin, h, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias)
+        hidden.append(h)
+
+        def view(t):
+            return t.view(B, g.Tp, -1)[:, :g.T]
+        out = Wav2Vec2BaseModelOutput(
+            last_hidden_state=view(h),
+            extract_features=None,
+            hidden_states=tuple(view(t) for t in hidden) if output_hidden_states else None,
+            attentions=None)
+        out._geom = g
+        out._frame_lens = frame_lens
+        out._flat_last = h
+        return out
+
+

@@ -64,6 +64,10 @@ typedef struct {
     int split_k;                    /* fp32 output only: K split into slabs in `workspace`, then reduced */
     int accumulate;                 /* fp32 output only: C += result */
     void* workspace; int64_t workspace_bytes;
+    /* optional 2-level batching (grouped positional conv: outer = utterance, inner = group); strides in elements */
+    int batch_outer, batch_inner;
+    int64_t batch_stride_a[2], batch_stride_b[2], batch_stride_c[2], batch_stride_bias[2], batch_stride_res[2],
+        batch_stride_aux[2];
 } aptai_gemm_desc;
 
 int aptai_gemm_bf16(const aptai_gemm_desc* desc, void* stream);
@@ -94,6 +98,69 @@ int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* ctx, float* 
 int aptai_attention_bwd(const void* qkv, const int32_t* lens, const void* ctx, const void* dctx, const float* lse2,
                         float* delta_ws, void* dqkv, int64_t B, int64_t Tp, int64_t H, int64_t heads, float scale,
                         float dropout_p, uint64_t seed, int dctx_zero_beyond_len, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ parameter prep
+ * fp32 master parameters -> bf16 compute copies (and the layouts the kernels want). */
+int aptai_cast_f32_to_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_dst, void* stream);
+/* nn.Conv1d weight [N][C][Kw] (HF:260-266) -> [N][Kw*C] bf16, K index = kw*C + c (channels-last frames) */
+int aptai_conv_weight_to_bf16(const float* src, void* dst, int64_t N, int64_t C, int64_t Kw, void* stream);
+/* positional conv (HF:329-356): weight_norm(dim=2) w = g*v/||v||_(0,1) ; v [H][H/groups][Kw], gain [Kw];
+ * w_fwd [groups][Cg][Kw*Cg] (forward), w_dgrad [groups][Cg][Kw*Cg] (flipped taps, in/out swapped; may be null);
+ * norm_ws fp32 [Kw] receives ||v|| per tap (needed by the weight-norm backward). */
+int aptai_posconv_weight(const float* v, const float* gain, float* norm_ws, void* w_fwd, void* w_dgrad, int64_t H,
+                         int64_t groups, int64_t Kw, void* stream);
+/* x [B*Tp][H] bf16 -> group-major, zero-gapped xg [groups][B][pad+Tp+pad][Cg] (gap rows must be pre-zeroed once);
+ * with u != null the packed value is x*gelu'(u) (backward of HF:362) and rowmajor_out also receives it. */
+int aptai_posconv_pack(const void* x, const void* u, void* xg, void* rowmajor_out, int64_t B, int64_t Tp, int64_t H,
+                       int64_t groups, int64_t pad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ frame masking
+ * In place on h [B*Tp][H] bf16: frames t >= min(lens[b], T) -> 0 (HF:678-681); frames with spec_mask[b][t] != 0
+ * (uint8 [B][T], sampled on the host exactly like HF:101-217) -> masked_spec_embed (HF:1292-1295). */
+int aptai_frame_mask_fwd(void* h, const int32_t* lens, const uint8_t* spec_mask, const float* embed, int64_t B, int64_t Tp,
+                         int64_t T, int64_t H, void* stream);
+int aptai_frame_mask_bwd(void* dy, const int32_t* lens, const uint8_t* spec_mask, float* dembed, void* workspace, int64_t B,
+                         int64_t Tp, int64_t T, int64_t H, void* stream);
+int64_t aptai_frame_mask_bwd_workspace_bytes(int64_t B, int64_t Tp, int64_t H);
+
+/* out[n] (+)= sum_rows x[row][n]  — bias gradients */
+int aptai_colsum_bf16(const void* x, int64_t ld, float* out, void* workspace, int64_t rows, int64_t N, int accumulate,
+                      void* stream);
+int64_t aptai_colsum_workspace_bytes(int64_t rows, int64_t N);
+
+/* y = keep ? x/(1-p) : 0 with the counter mask of (seed, element index) — standalone nn.Dropout forward/backward */
+int aptai_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ conv layer 0
+ * Conv1d(1,512,k=10,s=5) on the raw waveform fused with GroupNorm+GELU (mode 0, HF:302-323) or
+ * bias+LayerNorm+GELU (mode 1, HF:275-299).  audio fp32 [B][S]; out bf16 [B][T_alloc][512], frames >= T_real zeroed. */
+int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias, const float* gamma,
+                    const float* beta, int mode, float eps, void* out, int64_t T_real, int64_t T_alloc, int64_t C,
+                    int64_t Kw, int64_t stride, void* workspace, void* stream);
+int64_t aptai_conv0_workspace_bytes(int64_t B, int64_t T_real);
+
+/* ------------------------------------------------------------------------------------------------ APTAI heads
+ * a_tv = tanh(dropout(h)), a_ph = leaky_relu(dropout(h)) — the activations in front of the two head Linears
+ * (models/aptai.py:43-55); the Linears themselves run on aptai_gemm_bf16 with N padded to 64. */
+int aptai_head_act_fwd(const void* h, void* a_tv, void* a_ph, int64_t n, float p_tv, float p_ph, uint64_t seed, void* stream);
+int aptai_head_act_bwd(const void* h, const void* d_tv, const void* d_ph, void* dh, int64_t n, float p_tv, float p_ph,
+                       uint64_t seed, void* stream);
+/* LowPassFilterLayer (models/modules.py:46-61): 51-tap 'same' FIR along time, fp64 accumulate, per channel.
+ * x fp32 rows (b*rows_per_b_in + t) stride ldx; y fp32 or bf16 rows (b*rows_per_b_out + t) stride ldy; frames in
+ * [T, T_out) and channels in [C, C_out) of y are zero-filled.  Symmetric taps: the same call is its own backward. */
+int aptai_lowpass_fir(const float* x, int64_t ldx, int64_t rows_per_b_in, const double* taps, int64_t ntaps, void* y,
+                      int64_t ldy, int64_t rows_per_b_out, int out_bf16, int64_t B, int64_t T, int64_t T_out, int64_t C,
+                      int64_t C_out, void* stream);
+/* loss = w_mse * MSE(tv_pred[mask], tv_tgt[mask]) + w_ce * CE(logits[phn!=0], phn) and argmax (models/aptai.py:89-106;
+ * models/force_aptai.py:137-141 with w_ce = 0).  scalars fp32[5] = loss, mse, ce, #valid tv elements, #valid frames. */
+int aptai_aptai_loss_fwd(const float* tv_pred, const float* tv_tgt, const float* logits, int64_t ldl, int64_t rows_per_b,
+                         const int64_t* phn_tgt, int64_t B, int64_t T, int64_t n_tv, int64_t n_phn, float w_mse, float w_ce,
+                         float* scalars, int64_t* pred, void* workspace, void* stream);
+int aptai_aptai_loss_bwd(const float* tv_pred, const float* tv_tgt, const float* logits, int64_t ldl, int64_t rows_per_b,
+                         const int64_t* phn_tgt, int64_t B, int64_t T, int64_t n_tv, int64_t n_phn, float w_mse, float w_ce,
+                         const float* scalars, const float* grad_out, float* d_tv, void* d_logits_bf16, int64_t ldd,
+                         void* stream);
+int64_t aptai_aptai_loss_workspace_bytes(void);
 
 #ifdef __cplusplus
 }
