@@ -11,6 +11,9 @@ import os
 import subprocess
 import threading
 
+import torch  # noqa: F401  -- MUST precede the CDLL below: torch's bundled HIP runtime has to be the one this process
+#                              initialises; loading libaptai_hip.so first pulls in a second runtime that sees no device
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libaptai_hip.so")

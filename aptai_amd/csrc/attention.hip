@@ -426,7 +426,7 @@ extern "C" int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* c
     if (rc) return rc;
     APTAI_REQUIRE(ctx != nullptr, "aptai_attention_fwd: null ctx");
     a.ctx = (bf16_t*)ctx; a.lse2 = lse2;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B), dim3(256), 0,
+    APTAI_LAUNCH(attn_fwd_kernel, dim3((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream_, a);
     APTAI_CHECK_LAUNCH("attn_fwd_kernel");
     return APTAI_OK;
@@ -443,13 +443,13 @@ extern "C" int aptai_attention_bwd(const void* qkv, const int32_t* lens, const v
     a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.lse2 = (float*)lse2; a.delta = delta_ws; a.dqkv = (bf16_t*)dqkv;
     a.skip_pad_q = dctx_zero_beyond_len;
     const long waves = (long)B * Tp * heads;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)ceil_div(waves * 64, 256)), dim3(256), 0, stream,
+    APTAI_LAUNCH(attn_delta_kernel, dim3((unsigned)ceil_div(waves * 64, 256)), dim3(256), 0, stream,
                        (const bf16_t*)dctx, (const bf16_t*)ctx, delta_ws, (int)B, (int)Tp, (int)H, (int)heads);
     APTAI_CHECK_LAUNCH("attn_delta_kernel");
     dim3 grid((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, stream, a);
+    APTAI_LAUNCH(attn_bwd_dkdv_kernel, grid, dim3(256), 0, stream, a);
     APTAI_CHECK_LAUNCH("attn_bwd_dkdv_kernel");
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, a);
+    APTAI_LAUNCH(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, a);
     APTAI_CHECK_LAUNCH("attn_bwd_dq_kernel");
     return APTAI_OK;
 }

@@ -32,6 +32,12 @@ void aptai_set_error(const char* fmt, ...);
     do {                                                           \
         if (!(cond)) APTAI_FAIL(APTAI_ERR_INVALID, __VA_ARGS__);   \
     } while (0)
+// clear any stale error another library left on this thread, then launch (APTAI_CHECK_LAUNCH reads the launch's own status)
+#define APTAI_LAUNCH(...)             \
+    do {                              \
+        (void)hipGetLastError();      \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
 #define APTAI_CHECK_LAUNCH(name)                                                          \
     do {                                                                                  \
         hipError_t e__ = hipGetLastError();                                               \

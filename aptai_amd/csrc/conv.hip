@@ -185,7 +185,7 @@ extern "C" int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const f
     long blocks = ceil_div(T_alloc, 4 * 8);           // 8 frames per wave
     if (blocks > 1024) blocks = 1024;
     if (mode == 1) {
-        hipLaunchKernelGGL(conv0_layer_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, a);
+        APTAI_LAUNCH(conv0_layer_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, a);
         APTAI_CHECK_LAUNCH("conv0_layer_kernel");
         return APTAI_OK;
     }
@@ -194,12 +194,12 @@ extern "C" int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const f
     a.partials = (float*)workspace;
     float* stats = (float*)workspace + (long)B * a.nchunks * 2 * C0;
     a.stats = stats;
-    hipLaunchKernelGGL(conv0_stats_kernel, dim3((unsigned)a.nchunks, (unsigned)B), dim3(256), 0, stream, a);
+    APTAI_LAUNCH(conv0_stats_kernel, dim3((unsigned)a.nchunks, (unsigned)B), dim3(256), 0, stream, a);
     APTAI_CHECK_LAUNCH("conv0_stats_kernel");
-    hipLaunchKernelGGL(conv0_stats_final_kernel, dim3((unsigned)B), dim3(C0), 0, stream, (const float*)a.partials, stats,
+    APTAI_LAUNCH(conv0_stats_final_kernel, dim3((unsigned)B), dim3(C0), 0, stream, (const float*)a.partials, stats,
                        a.nchunks, (int)T_real, eps);
     APTAI_CHECK_LAUNCH("conv0_stats_final_kernel");
-    hipLaunchKernelGGL(conv0_group_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, a);
+    APTAI_LAUNCH(conv0_group_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, a);
     APTAI_CHECK_LAUNCH("conv0_group_kernel");
     return APTAI_OK;
 }

@@ -223,9 +223,9 @@ extern "C" int aptai_cast_f32_to_bf16(const float* src, void* dst, int64_t rows,
     APTAI_REQUIRE(src && dst && rows > 0 && cols > 0, "aptai_cast_f32_to_bf16: bad arguments");
     if (ld_dst == cols && (rows * cols) % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0)) {
         const long n4 = rows * cols / 4;
-        hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n4);
+        APTAI_LAUNCH(cast_f32_bf16_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n4);
     } else {
-        hipLaunchKernelGGL(cast_rows_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, src,
+        APTAI_LAUNCH(cast_rows_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, src,
                            (bf16_t*)dst, (long)rows, (long)cols, (long)ld_dst);
     }
     APTAI_CHECK_LAUNCH("cast kernel");
@@ -234,7 +234,7 @@ extern "C" int aptai_cast_f32_to_bf16(const float* src, void* dst, int64_t rows,
 
 extern "C" int aptai_conv_weight_to_bf16(const float* src, void* dst, int64_t N, int64_t C, int64_t Kw, void* stream) {
     APTAI_REQUIRE(src && dst && N > 0 && C > 0 && Kw > 0, "aptai_conv_weight_to_bf16: bad arguments");
-    hipLaunchKernelGGL(conv_weight_kernel, dim3(grid_for(N * C * Kw)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
+    APTAI_LAUNCH(conv_weight_kernel, dim3(grid_for(N * C * Kw)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
                        (int)N, (int)C, (int)Kw);
     APTAI_CHECK_LAUNCH("conv_weight_kernel");
     return APTAI_OK;
@@ -245,9 +245,9 @@ extern "C" int aptai_posconv_weight(const float* v, const float* gain, float* no
     APTAI_REQUIRE(v && gain && norm_ws && w_fwd, "aptai_posconv_weight: null pointer");
     APTAI_REQUIRE(groups > 0 && H % groups == 0 && (H / groups) % 8 == 0, "aptai_posconv_weight: H=%ld groups=%ld", (long)H, (long)groups);
     const int Cg = (int)(H / groups);
-    hipLaunchKernelGGL(posconv_norm_kernel, dim3((unsigned)Kw), dim3(256), 0, (hipStream_t)stream, v, norm_ws, (long)H * Cg, (int)Kw);
+    APTAI_LAUNCH(posconv_norm_kernel, dim3((unsigned)Kw), dim3(256), 0, (hipStream_t)stream, v, norm_ws, (long)H * Cg, (int)Kw);
     APTAI_CHECK_LAUNCH("posconv_norm_kernel");
-    hipLaunchKernelGGL(posconv_weight_kernel, dim3(grid_for(H * Cg * Kw)), dim3(256), 0, (hipStream_t)stream, v, gain,
+    APTAI_LAUNCH(posconv_weight_kernel, dim3(grid_for(H * Cg * Kw)), dim3(256), 0, (hipStream_t)stream, v, gain,
                        (const float*)norm_ws, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, (int)H, Cg, (int)Kw);
     APTAI_CHECK_LAUNCH("posconv_weight_kernel");
     return APTAI_OK;
@@ -257,7 +257,7 @@ extern "C" int aptai_posconv_pack(const void* x, const void* u, void* xg, void* 
                                   int64_t H, int64_t groups, int64_t pad, void* stream) {
     APTAI_REQUIRE(x && xg, "aptai_posconv_pack: null pointer");
     APTAI_REQUIRE(groups > 0 && H % groups == 0 && (H / groups) % 4 == 0, "aptai_posconv_pack: H=%ld groups=%ld", (long)H, (long)groups);
-    hipLaunchKernelGGL(posconv_pack_kernel, dim3(grid_for(B * Tp * H / 4)), dim3(256), 0, (hipStream_t)stream,
+    APTAI_LAUNCH(posconv_pack_kernel, dim3(grid_for(B * Tp * H / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x, (const bf16_t*)u, (bf16_t*)xg, (bf16_t*)rowmajor_out, (int)B, (int)Tp, (int)H,
                        (int)(H / groups), (int)pad);
     APTAI_CHECK_LAUNCH("posconv_pack_kernel");
@@ -268,7 +268,7 @@ extern "C" int aptai_frame_mask_fwd(void* h, const int32_t* lens, const uint8_t*
                                     int64_t Tp, int64_t T, int64_t H, void* stream) {
     APTAI_REQUIRE(h && lens && H % 4 == 0, "aptai_frame_mask_fwd: bad arguments");
     APTAI_REQUIRE(!spec_mask || embed, "aptai_frame_mask_fwd: spec mask without masked_spec_embed");
-    hipLaunchKernelGGL(frame_mask_kernel, dim3(grid_for(B * Tp * H / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)h, lens,
+    APTAI_LAUNCH(frame_mask_kernel, dim3(grid_for(B * Tp * H / 4)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)h, lens,
                        spec_mask, embed, (int)B, (int)Tp, (int)T, (int)H);
     APTAI_CHECK_LAUNCH("frame_mask_kernel");
     return APTAI_OK;
@@ -284,11 +284,11 @@ extern "C" int aptai_frame_mask_bwd(void* dy, const int32_t* lens, const uint8_t
     const long blocks = ceil_div(B * Tp, MASK_BWD_RPB);
     const bool want = spec_mask && dembed;
     APTAI_REQUIRE(!want || workspace, "aptai_frame_mask_bwd: workspace needed for dembed");
-    hipLaunchKernelGGL(frame_mask_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dy, lens,
+    APTAI_LAUNCH(frame_mask_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dy, lens,
                        spec_mask, want ? (float*)workspace : nullptr, (int)B, (int)Tp, (int)T, (int)H, MASK_BWD_RPB);
     APTAI_CHECK_LAUNCH("frame_mask_bwd_kernel");
     if (want) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(H, 256)), dim3(256), 0, (hipStream_t)stream,
+        APTAI_LAUNCH(reduce_partials_kernel, dim3((unsigned)ceil_div(H, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)workspace, dembed, (int)blocks, (int)H, 0);
         APTAI_CHECK_LAUNCH("reduce_partials_kernel");
     }
@@ -301,10 +301,10 @@ extern "C" int aptai_colsum_bf16(const void* x, int64_t ld, float* out, void* wo
                                  int accumulate, void* stream) {
     APTAI_REQUIRE(x && out && workspace && rows > 0 && N % 4 == 0 && ld % 4 == 0, "aptai_colsum_bf16: bad arguments");
     const long blocks = ceil_div(rows, COLSUM_RPB);
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ld,
+    APTAI_LAUNCH(colsum_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ld,
                        (float*)workspace, (long)rows, (int)N, COLSUM_RPB);
     APTAI_CHECK_LAUNCH("colsum_bf16_kernel");
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream,
+    APTAI_LAUNCH(reduce_partials_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, out, (int)blocks, (int)N, accumulate);
     APTAI_CHECK_LAUNCH("reduce_partials_kernel");
     return APTAI_OK;
@@ -314,7 +314,7 @@ extern "C" int aptai_head_act_fwd(const void* h, void* a_tv, void* a_ph, int64_t
                                   void* stream) {
     APTAI_REQUIRE(h && a_tv && a_ph && n > 0, "aptai_head_act_fwd: bad arguments");
     const uint32_t t1 = drop_thr16(p_tv), t2 = drop_thr16(p_ph);
-    hipLaunchKernelGGL(head_act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+    APTAI_LAUNCH(head_act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                        (bf16_t*)a_tv, (bf16_t*)a_ph, (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t1, t2, drop_scale(t1),
                        drop_scale(t2));
     APTAI_CHECK_LAUNCH("head_act_fwd_kernel");
@@ -325,7 +325,7 @@ extern "C" int aptai_head_act_bwd(const void* h, const void* d_tv, const void* d
                                   float p_ph, uint64_t seed, void* stream) {
     APTAI_REQUIRE(h && d_tv && d_ph && dh && n > 0, "aptai_head_act_bwd: bad arguments");
     const uint32_t t1 = drop_thr16(p_tv), t2 = drop_thr16(p_ph);
-    hipLaunchKernelGGL(head_act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+    APTAI_LAUNCH(head_act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                        (const bf16_t*)d_tv, (const bf16_t*)d_ph, (bf16_t*)dh, (long)n, (uint32_t)seed, (uint32_t)(seed >> 32),
                        t1, t2, drop_scale(t1), drop_scale(t2));
     APTAI_CHECK_LAUNCH("head_act_bwd_kernel");
@@ -335,7 +335,7 @@ extern "C" int aptai_head_act_bwd(const void* h, const void* d_tv, const void* d
 extern "C" int aptai_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream) {
     APTAI_REQUIRE(x && y && n > 0, "aptai_dropout_bf16: bad arguments");
     const uint32_t t = drop_thr16(p);
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
+    APTAI_LAUNCH(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
                        (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t, drop_scale(t));
     APTAI_CHECK_LAUNCH("dropout_kernel");
     return APTAI_OK;

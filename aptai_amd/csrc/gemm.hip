@@ -248,7 +248,7 @@ int launch_gemm(const GemmArgs& g, int nbatch, int nsplit, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid(g.tiles_m * g.tiles_n, nbatch, nsplit);
-    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), 2 * STAGE_BYTES, stream, g);
+    APTAI_LAUNCH(kern, grid, dim3(NTHREADS), 2 * STAGE_BYTES, stream, g);
     APTAI_CHECK_LAUNCH("gemm_kernel");
     return APTAI_OK;
 }
@@ -331,7 +331,7 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     if (f32 && (nsplit > 1 || d->accumulate)) {
         const long n4 = (long)d->M * d->N / 4;
         int blocks = (int)(n4 / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)d->workspace, final_out,
+        APTAI_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)d->workspace, final_out,
                            n4, g.slab_stride / 4, nsplit, d->accumulate ? 1 : 0);
         APTAI_CHECK_LAUNCH("splitk_reduce_kernel");
     }

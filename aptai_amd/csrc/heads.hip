@@ -155,10 +155,10 @@ extern "C" int aptai_lowpass_fir(const float* x, int64_t ldx, int64_t rows_per_b
     const long n = B * T_out * C_out;
     unsigned blocks = (unsigned)(ceil_div(n, 256) > 2048 ? 2048 : ceil_div(n, 256));
     if (out_bf16)
-        hipLaunchKernelGGL(fir_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (long)rows_per_b_in,
+        APTAI_LAUNCH(fir_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (long)rows_per_b_in,
                            taps, (int)ntaps, y, (long)ldy, (long)rows_per_b_out, (int)B, (int)T, (int)T_out, (int)C, (int)C_out);
     else
-        hipLaunchKernelGGL(fir_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (long)rows_per_b_in,
+        APTAI_LAUNCH(fir_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (long)rows_per_b_in,
                            taps, (int)ntaps, y, (long)ldy, (long)rows_per_b_out, (int)B, (int)T, (int)T_out, (int)C, (int)C_out);
     APTAI_CHECK_LAUNCH("fir_kernel");
     return APTAI_OK;
@@ -186,9 +186,9 @@ extern "C" int aptai_aptai_loss_fwd(const float* tv_pred, const float* tv_tgt, c
     if (rc) return rc;
     APTAI_REQUIRE(scalars && workspace, "aptai_aptai_loss_fwd: null pointer");
     a.partials = (float*)workspace; a.scalars = scalars; a.pred = pred;
-    hipLaunchKernelGGL(loss_fwd_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
+    APTAI_LAUNCH(loss_fwd_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, (hipStream_t)stream, a);
     APTAI_CHECK_LAUNCH("loss_fwd_kernel");
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, LOSS_BLOCKS, scalars,
+    APTAI_LAUNCH(loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, LOSS_BLOCKS, scalars,
                        w_mse, w_ce);
     APTAI_CHECK_LAUNCH("loss_final_kernel");
     return APTAI_OK;
@@ -204,7 +204,7 @@ extern "C" int aptai_aptai_loss_bwd(const float* tv_pred, const float* tv_tgt, c
     APTAI_REQUIRE(scalars && d_tv && d_logits_bf16 && ldd >= n_phn, "aptai_aptai_loss_bwd: bad arguments");
     a.scalars = (float*)scalars;
     const long rows = B * rows_per_b;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, a, grad_out, d_tv,
+    APTAI_LAUNCH(loss_bwd_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, a, grad_out, d_tv,
                        (bf16_t*)d_logits_bf16, (long)ldd);
     APTAI_CHECK_LAUNCH("loss_bwd_kernel");
     return APTAI_OK;

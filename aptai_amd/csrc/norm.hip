@@ -158,7 +158,7 @@ extern "C" int aptai_layernorm_fwd(const void* x, const float* gamma, const floa
     APTAI_REQUIRE(cols % 256 == 0 && cols >= 256 && cols <= 1024, "aptai_layernorm_fwd: cols=%ld (need 256..1024, %%256)", (long)cols);
     long blocks = ceil_div(rows, 4);
     if (blocks > 2048) blocks = 2048;
-#define LN_FWD(NCH) hipLaunchKernelGGL(ln_fwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, (long)rows, eps, gelu_after)
+#define LN_FWD(NCH) APTAI_LAUNCH(ln_fwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, (long)rows, eps, gelu_after)
     switch (cols / 256) {
         case 1: LN_FWD(1); break;
         case 2: LN_FWD(2); break;
@@ -189,7 +189,7 @@ extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* m
     const uint32_t thr = drop_thr16(dropout_p);
     void* dxd = thr ? dx_drop : nullptr;
     if (dx_drop && !thr) APTAI_FAIL(APTAI_ERR_INVALID, "aptai_layernorm_bwd: dx_drop given with dropout_p == 0");
-#define LN_BWD(NCH) hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows)
+#define LN_BWD(NCH) APTAI_LAUNCH(ln_bwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows)
     switch (cols / 256) {
         case 1: LN_BWD(1); break;
         case 2: LN_BWD(2); break;
@@ -200,7 +200,7 @@ extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* m
     APTAI_CHECK_LAUNCH("ln_bwd_kernel");
     if (dgamma || dbeta) {
         const int n = 2 * (int)cols;
-        hipLaunchKernelGGL(colsum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+        APTAI_LAUNCH(colsum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
                            (const float*)workspace, dgamma, dbeta, (int)blocks, (int)cols);
         APTAI_CHECK_LAUNCH("colsum_partials_kernel");
     }

@@ -1,0 +1,133 @@
+"""Pure data parallelism for the APTAI hot path: one process per GPU, utterances sharded across ranks, one
+bucketed gradient all-reduce per step over RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm), overlapped
+with the rest of backward.  The reference is single-device: this is new functionality whose
+parity definition is "averaged DP gradients == single-process gradients of the concatenated batch".
+
+Design for xGMI (7 point-to-point links x ~153 GB/s per GPU, no switch): few, large buckets (default 48 MB
+bf16 => ~13 all-reduces for wav2vec2-large) so each collective is bandwidth- not latency-bound; buckets are
+filled in reverse parameter order (the order backward produces gradients) and launched from
+post-accumulate-grad hooks on a side stream so the collective of bucket k overlaps the backward of bucket k+1.
+Works unchanged on CPU tensors with the gloo backend (used by the world_size-2 tests).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradBucketReducer:
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 48.0,
+                 comm_dtype: Optional[torch.dtype] = None, process_group=None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.comm_dtype = comm_dtype
+        cap = int(bucket_mb * 1024 * 1024)
+        self.buckets: List[List[torch.nn.Parameter]] = []
+        cur, cur_bytes = [], 0
+        esize = torch.empty(0, dtype=comm_dtype).element_size() if comm_dtype else 4
+        for p in reversed(self.params):
+            cur.append(p)
+            cur_bytes += p.numel() * esize
+            if cur_bytes >= cap:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {id(p): bi for bi, b in enumerate(self.buckets) for p in b}
+        self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._pending = [0] * len(self.buckets)
+        self._handles = [None] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._hooks = []
+        self._stream = None
+        if self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.reset()
+
+    # ------------------------------------------------------------------ per-step protocol
+    def reset(self):
+        for bi, b in enumerate(self.buckets):
+            self._pending[bi] = len(b)
+            self._handles[bi] = None
+            self._launched[bi] = False
+
+    def _on_grad(self, p):
+        bi = self._bucket_of[id(p)]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _flat_for(self, bi):
+        b = self.buckets[bi]
+        n = sum(p.numel() for p in b)
+        dt = self.comm_dtype or b[0].dtype
+        f = self._flat[bi]
+        if f is None or f.numel() != n or f.device != b[0].device:
+            f = torch.empty(n, device=b[0].device, dtype=dt)
+            self._flat[bi] = f
+        return f
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        flat = self._flat_for(bi)
+        views, off = [], 0
+        for p in b:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b]
+        if flat.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                torch._foreach_copy_(views, grads)
+                self._handles[bi] = dist.all_reduce(flat, group=self.group, async_op=True)
+        else:
+            torch._foreach_copy_(views, grads)
+            self._handles[bi] = dist.all_reduce(flat, group=self.group, async_op=True)
+        self._launched[bi] = True
+
+    def finish(self):
+        """Call after ``loss.backward()``: launches incomplete buckets (parameters that received no gradient this
+        step, e.g. LayerDrop'd layers, contribute zeros), waits, averages and writes the result back to ``.grad``."""
+        if self.world == 1:
+            return
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
+                self._launch(bi)
+        inv = 1.0 / self.world
+        for bi, b in enumerate(self.buckets):
+            self._handles[bi].wait()
+            flat = self._flat[bi]
+            if flat.is_cuda:
+                torch.cuda.current_stream().wait_stream(self._stream)
+            off = 0
+            outs, srcs = [], []
+            for p in b:
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                outs.append(p.grad)
+                srcs.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            torch._foreach_copy_(outs, srcs)
+            torch._foreach_mul_(outs, inv)
+        self.reset()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def shard_batch(batch: dict, rank: int, world: int) -> dict:
+    """Contiguous utterance shards of a global batch dict."""
+    out = {}
+    for k, v in batch.items():
+        n = v.shape[0]
+        per = n // world
+        out[k] = v[rank * per:(rank + 1) * per]
+    return out

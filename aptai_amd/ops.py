@@ -29,6 +29,29 @@ class GemmDesc(ctypes.Structure):
                 ("batch_stride_bias", c_i64 * 2), ("batch_stride_res", c_i64 * 2), ("batch_stride_aux", c_i64 * 2)]
 
 
+class GemmProbe:
+    """Brackets every aptai_gemm_bf16 launch of one operand-layout family with HIP events on the launch stream and
+    accumulates (algorithmic flops, elapsed ms): bench.py's live roofline measurement of the dominant kernel."""
+
+    def __init__(self, a_kmajor=False, b_kmajor=False, out_f32=False):
+        self.key = (bool(a_kmajor), bool(b_kmajor), bool(out_f32))
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        flops = sum(f for f, _, _ in self.records)
+        ms = sum(s.elapsed_time(e) for _, s, e in self.records)
+        return dict(launches=len(self.records), flops=flops, ms=ms)
+
+
+_probe: Optional["GemmProbe"] = None
+
+
+def set_gemm_probe(p: Optional["GemmProbe"]) -> None:
+    global _probe
+    _probe = p
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -93,6 +116,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
         if workspace is None or workspace.numel() * workspace.element_size() < need:
             workspace = torch.empty(need, device=a.device, dtype=torch.uint8)
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    pr = _probe
+    if pr is not None and pr.key == (bool(a_kmajor), bool(b_kmajor), bool(out_f32)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().aptai_gemm_bf16(ctypes.byref(d), c_void_p(_stream())), "aptai_gemm_bf16")
+        e1.record()
+        nb = (batch.get("outer", 1) * batch.get("inner", 1)) if batch else 1
+        pr.records.append((2.0 * M * N * K * nb, e0, e1))
+        return out
     _lib.check(_lib.lib().aptai_gemm_bf16(ctypes.byref(d), c_void_p(_stream())), "aptai_gemm_bf16")
     return out
 

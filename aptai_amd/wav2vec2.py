@@ -382,6 +382,8 @@ class Wav2Vec2Model(nn.Module):
         self._scratch_owner = {}
         self._step = 0
         self.base_seed = 0x5EED
+        # LayerDrop coins come from a dedicated generator so that data-parallel ranks (same seed) drop the same layers
+        self._layerdrop_gen = torch.Generator().manual_seed(0x1A7E)
 
     # ------------------------------------------------------------------ reference-facing helpers
     @classmethod
@@ -591,7 +593,7 @@ class Wav2Vec2Model(nn.Module):
         hidden = []
         for i, layer in enumerate(self.encoder.layers):
             hidden.append(h)
-            skip = training and (float(torch.rand([])) < cfg.layerdrop)
+            skip = training and cfg.layerdrop > 0 and (float(torch.rand([], generator=self._layerdrop_gen)) < cfg.layerdrop)
             if skip:
                 continue
             w, lin_params = self._layer_weights(i, g.M)
