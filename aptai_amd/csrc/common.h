@@ -77,6 +77,23 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16 output grid): one v_rcp + one v_exp + 6 fma
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(e, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_fast_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
+    return fmaf(x * 0.39894228040143268f, __expf(-0.5f * x * x), cdf);
+}
+
 // ---------------------------------------------------------------------------------- counter RNG (dropout)
 // One 32-bit hash per PAIR of elements (16 bits each): keep iff half >= thr16.  Forward and backward
 // regenerate the same mask from (seed, logical element index), whatever their thread mapping.
@@ -94,6 +111,10 @@ __device__ __forceinline__ bool drop_keep(uint64_t e, uint32_t s0, uint32_t s1, 
     const uint32_t h = rng_hash((uint32_t)(e >> 1) ^ (uint32_t)(e >> 33) * 0x85ebca6bu, s0, s1);
     const uint32_t half = (e & 1) ? (h >> 16) : (h & 0xffffu);
     return half >= thr16;
+}
+// both 16-bit lanes of the pair containing element e (e even)
+__device__ __forceinline__ uint32_t drop_hash_pair(uint64_t e, uint32_t s0, uint32_t s1) {
+    return rng_hash((uint32_t)(e >> 1) ^ (uint32_t)(e >> 33) * 0x85ebca6bu, s0, s1);
 }
 static inline uint32_t drop_thr16(float p) {
     if (p <= 0.f) return 0;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args a) {
             for (int j = 0; j < 8; ++j) { const float d = v[j] - mu; q += d * d; }
             const float rs = rsqrtf(wave_sum(q) * (1.0f / C0) + a.eps);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = gelu_erf((v[j] - mu) * rs * gm[j] + bt[j]);
+            for (int j = 0; j < 8; ++j) o[j] = gelu_fast((v[j] - mu) * rs * gm[j] + bt[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = 0.f;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args a) {
             float v[8];
             conv_frame(xb + (long)t * STRIDE, w, bias, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = gelu_erf(fmaf(v[j], sc[j], sh[j]));
+            for (int j = 0; j < 8; ++j) o[j] = gelu_fast(fmaf(v[j], sc[j], sh[j]));
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = 0.f;

@@ -88,8 +88,8 @@ __global__ void posconv_pack_kernel(const bf16_t* __restrict__ x, const bf16_t* 
         u32x2 p = *(const u32x2*)(x + e);
         if (u) {
             const u32x2 q = *(const u32x2*)(u + e);
-            p = (u32x2){pack2bf(lo_bf(p[0]) * gelu_erf_grad(lo_bf(q[0])), hi_bf(p[0]) * gelu_erf_grad(hi_bf(q[0]))),
-                        pack2bf(lo_bf(p[1]) * gelu_erf_grad(lo_bf(q[1])), hi_bf(p[1]) * gelu_erf_grad(hi_bf(q[1])))};
+            p = (u32x2){pack2bf(lo_bf(p[0]) * gelu_fast_grad(lo_bf(q[0])), hi_bf(p[0]) * gelu_fast_grad(hi_bf(q[0]))),
+                        pack2bf(lo_bf(p[1]) * gelu_fast_grad(lo_bf(q[1])), hi_bf(p[1]) * gelu_fast_grad(hi_bf(q[1])))};
             if (rowmajor_out) *(u32x2*)(rowmajor_out + e) = p;
         }
         const int grp = col / Cg, c = col % Cg;          // Cg % 4 == 0: the 4 elements stay in one group
@@ -148,29 +148,46 @@ __global__ void frame_mask_bwd_kernel(bf16_t* __restrict__ dy, const int* __rest
     }
 }
 
-// ---- column sums of a bf16 matrix (bias gradients): partials[block][N] then a final reduction
-__global__ void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, float* __restrict__ partials, long rows, int N,
-                                   int rows_per_block) {
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    for (int c4 = threadIdx.x; c4 < N / 4; c4 += blockDim.x) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int rr = 0; rr < rows_per_block; ++rr) {
-            const long row = r0 + rr;
-            if (row >= rows) break;
-            const u32x2 p = *(const u32x2*)(x + row * ld + c4 * 4);
+// ---- column sums of a bf16 matrix (bias gradients), HBM-bound: block = strip of 256 columns x COLSUM_RPB rows;
+// each wave streams rows with 8-byte loads (lane = 4 columns), the 4 waves combine through LDS -> partials[rowblk][N]
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, float* __restrict__ partials,
+                                                          long rows, int N, int rows_per_block) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + lane * 4;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    r1 = r1 < rows ? r1 : rows;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < N) {
+        for (long row = r0 + wave; row < r1; row += 4) {
+            const u32x2 p = *(const u32x2*)(x + row * ld + col);
             acc[0] += lo_bf(p[0]); acc[1] += hi_bf(p[0]); acc[2] += lo_bf(p[1]); acc[3] += hi_bf(p[1]);
         }
-        *(f32x4*)(partials + (long)blockIdx.x * N + c4 * 4) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][lane * 4 + r] = acc[r];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < N)
+        partials[(long)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ partials, float* __restrict__ out, int nblocks, int N,
-                                       int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    float s = accumulate ? out[c] : 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partials[(long)b * N + c];
-    out[c] = s;
+// out[c] (+)= sum_b partials[b][c]: block = 64 columns x 4 slices
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, float* __restrict__ out, int nblocks,
+                                                              int N, int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < N)
+        for (int b = slice; b < nblocks; b += 4) s += partials[(long)b * N + c];
+    red[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && c < N) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // ---- APTAI head activations: a_tv = tanh(drop(h)), a_ph = leaky_relu(drop(h))   (models/aptai.py:43-55)
@@ -288,23 +305,23 @@ extern "C" int aptai_frame_mask_bwd(void* dy, const int32_t* lens, const uint8_t
                        spec_mask, want ? (float*)workspace : nullptr, (int)B, (int)Tp, (int)T, (int)H, MASK_BWD_RPB);
     APTAI_CHECK_LAUNCH("frame_mask_bwd_kernel");
     if (want) {
-        APTAI_LAUNCH(reduce_partials_kernel, dim3((unsigned)ceil_div(H, 256)), dim3(256), 0, (hipStream_t)stream,
+        APTAI_LAUNCH(reduce_partials_kernel, dim3((unsigned)ceil_div(H, 64)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)workspace, dembed, (int)blocks, (int)H, 0);
         APTAI_CHECK_LAUNCH("reduce_partials_kernel");
     }
     return APTAI_OK;
 }
 
-static const int COLSUM_RPB = 64;
+static const int COLSUM_RPB = 256;
 extern "C" int64_t aptai_colsum_workspace_bytes(int64_t rows, int64_t N) { return ceil_div(rows, COLSUM_RPB) * N * 4; }
 extern "C" int aptai_colsum_bf16(const void* x, int64_t ld, float* out, void* workspace, int64_t rows, int64_t N,
                                  int accumulate, void* stream) {
     APTAI_REQUIRE(x && out && workspace && rows > 0 && N % 4 == 0 && ld % 4 == 0, "aptai_colsum_bf16: bad arguments");
     const long blocks = ceil_div(rows, COLSUM_RPB);
-    APTAI_LAUNCH(colsum_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (long)ld,
-                       (float*)workspace, (long)rows, (int)N, COLSUM_RPB);
+    APTAI_LAUNCH(colsum_bf16_kernel, dim3((unsigned)ceil_div(N, 256), (unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                 (const bf16_t*)x, (long)ld, (float*)workspace, (long)rows, (int)N, COLSUM_RPB);
     APTAI_CHECK_LAUNCH("colsum_bf16_kernel");
-    APTAI_LAUNCH(reduce_partials_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream,
+    APTAI_LAUNCH(reduce_partials_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, out, (int)blocks, (int)N, accumulate);
     APTAI_CHECK_LAUNCH("reduce_partials_kernel");
     return APTAI_OK;

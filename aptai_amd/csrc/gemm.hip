@@ -21,6 +21,8 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int NTHREADS = 256;
 constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;   // 32 KiB
 constexpr int OPER_BYTES = BM * BK * 2;                // 16 KiB per operand tile
+constexpr int EPI_PITCH = BN * 4 + 16;                 // fp32 epilogue tile row pitch (bytes)
+constexpr int SMEM_BYTES = BM * EPI_PITCH > 2 * STAGE_BYTES ? BM * EPI_PITCH : 2 * STAGE_BYTES;
 
 struct GemmArgs {
     const bf16_t* A; long lda;
@@ -165,66 +167,84 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
     }
 
     // ------------------------------------------------------------------ epilogue
-    // acc[i][j][r]: m = m0 + wm*64 + i*16 + (lane&15);  n = n0 + wn*64 + j*16 + (lane>>4)*4 + r
-    const int flags = g.flags;
+    // Phase 1: accumulators -> fp32 LDS tile [128][128] (row pitch 528 B: conflict-free 16-B writes of 16 rows).
+    // acc[i][j][r]: m = wm*64 + i*16 + (lane&15);  n = wn*64 + j*16 + (lane>>4)*4 + r
+    __syncthreads();                                   // every wave is done reading the staging buffers
+    {
+        char* ct = smem;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-        if (m >= g.M) continue;
+        for (int i = 0; i < 4; ++i) {
+            const int ml = wm * 64 + i * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (n >= g.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (OUT_F32) {
-                float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
-                if (flags & APTAI_EPI_ALPHA) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
-                }
-                if (flags & APTAI_EPI_BIAS) {
-                    const f32x4 b = *(const f32x4*)(g.bias + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += b[r];
-                }
-                *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
-            } else {
-                if (flags & APTAI_EPI_ALPHA) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
-                }
-                if (flags & APTAI_EPI_BIAS) {
-                    const f32x4 b = *(const f32x4*)(g.bias + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += b[r];
-                }
-                if (g.out_pre) {
-                    u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                    *(u32x2*)(g.out_pre + (long)m * g.ldc + n) = o;
-                }
-                if (flags & APTAI_EPI_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                }
-                if (flags & APTAI_EPI_DROPOUT) {
-                    const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = drop_keep(e + r, g.seed0, g.seed1, g.thr16) ? v[r] * g.dscale : 0.f;
-                }
-                if (flags & APTAI_EPI_DGELU) {
-                    const u32x2 a = *(const u32x2*)(g.aux + (long)m * g.ldaux + n);
-                    v[0] *= gelu_erf_grad(lo_bf(a[0])); v[1] *= gelu_erf_grad(hi_bf(a[0]));
-                    v[2] *= gelu_erf_grad(lo_bf(a[1])); v[3] *= gelu_erf_grad(hi_bf(a[1]));
-                }
-                if (flags & APTAI_EPI_RESIDUAL) {
-                    const u32x2 a = *(const u32x2*)(g.residual + (long)m * g.ldr + n);
-                    v[0] += lo_bf(a[0]); v[1] += hi_bf(a[0]); v[2] += lo_bf(a[1]); v[3] += hi_bf(a[1]);
-                }
-                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                *(u32x2*)((bf16_t*)g.C + (long)m * g.ldc + n) = o;
+            for (int j = 0; j < 4; ++j) {
+                const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
+                *(f32x4*)(ct + ml * EPI_PITCH + nl * 4) = acc[i][j];
             }
         }
+    }
+    __syncthreads();
+    // Phase 2: thread -> 8 consecutive columns of one row per pass (16 threads cover a 512-B row): every global
+    // access of the epilogue (residual, aux, out_pre, C) is a coalesced 16/32-byte-per-lane row segment.
+    const int flags = g.flags;
+    const int cl = (tid & 15) * 8;                     // column inside the tile, fixed per thread
+    const int n = n0 + cl;
+    const bool n_ok = n < g.N;
+    float bias8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bias8[r] = 0.f;
+    if ((flags & APTAI_EPI_BIAS) && n_ok) {
+        const f32x4 b0 = *(const f32x4*)(g.bias + n), b1 = *(const f32x4*)(g.bias + n + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bias8[r] = b0[r]; bias8[4 + r] = b1[r]; }
+    }
+    const float alpha = (flags & APTAI_EPI_ALPHA) ? g.alpha : 1.0f;
+#pragma unroll 2
+    for (int pass = 0; pass < 8; ++pass) {
+        const int ml = pass * 16 + (tid >> 4);
+        const int m = m0 + ml;
+        if (m >= g.M || !n_ok) continue;
+        const f32x4 v0 = *(const f32x4*)(smem + ml * EPI_PITCH + cl * 4);
+        const f32x4 v1 = *(const f32x4*)(smem + ml * EPI_PITCH + cl * 4 + 16);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fmaf(v[r], alpha, bias8[r]);
+        if (OUT_F32) {
+            float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
+            *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            continue;
+        }
+        if (g.out_pre)
+            *(u32x4*)(g.out_pre + (long)m * g.ldc + n) =
+                (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        if (flags & APTAI_EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
+        }
+        if (flags & APTAI_EPI_DROPOUT) {
+            const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                const uint32_t hsh = drop_hash_pair(e + r, g.seed0, g.seed1);
+                v[r] = (hsh & 0xffffu) >= g.thr16 ? v[r] * g.dscale : 0.f;
+                v[r + 1] = (hsh >> 16) >= g.thr16 ? v[r + 1] * g.dscale : 0.f;
+            }
+        }
+        if (flags & APTAI_EPI_DGELU) {
+            const u32x4 a = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[2 * r] *= gelu_fast_grad(lo_bf(a[r]));
+                v[2 * r + 1] *= gelu_fast_grad(hi_bf(a[r]));
+            }
+        }
+        if (flags & APTAI_EPI_RESIDUAL) {
+            const u32x4 a = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[2 * r] += lo_bf(a[r]); v[2 * r + 1] += hi_bf(a[r]); }
+        }
+        *(u32x4*)((bf16_t*)g.C + (long)m * g.ldc + n) =
+            (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
     }
 }
 
@@ -244,11 +264,11 @@ int launch_gemm(const GemmArgs& g, int nbatch, int nsplit, hipStream_t stream) {
     auto kern = gemm_kernel<A_KM, B_KM, OUT_F32>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         attr_set = true;
     }
     dim3 grid(g.tiles_m * g.tiles_n, nbatch, nsplit);
-    APTAI_LAUNCH(kern, grid, dim3(NTHREADS), 2 * STAGE_BYTES, stream, g);
+    APTAI_LAUNCH(kern, grid, dim3(NTHREADS), SMEM_BYTES, stream, g);
     APTAI_CHECK_LAUNCH("gemm_kernel");
     return APTAI_OK;
 }
@@ -263,7 +283,10 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     APTAI_REQUIRE(d->K % BK == 0, "aptai_gemm_bf16: K=%ld must be a multiple of %d", (long)d->K, BK);
     APTAI_REQUIRE(d->N % 8 == 0, "aptai_gemm_bf16: N=%ld must be a multiple of 8", (long)d->N);
     APTAI_REQUIRE(d->A && d->B && d->C, "aptai_gemm_bf16: null operand");
-    APTAI_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 4 == 0, "aptai_gemm_bf16: leading dims must keep 16-B alignment");
+    APTAI_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 8 == 0, "aptai_gemm_bf16: leading dims must keep 16-B alignment");
+    if (d->residual) APTAI_REQUIRE(d->ldr % 8 == 0 && (uintptr_t)d->residual % 16 == 0, "aptai_gemm_bf16: residual must be 16-B aligned");
+    if (d->aux) APTAI_REQUIRE(d->ldaux % 8 == 0 && (uintptr_t)d->aux % 16 == 0, "aptai_gemm_bf16: aux must be 16-B aligned");
+    if (d->bias) APTAI_REQUIRE((uintptr_t)d->bias % 16 == 0, "aptai_gemm_bf16: bias must be 16-B aligned");
     APTAI_REQUIRE(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0) && ((uintptr_t)d->C % 16 == 0),
                   "aptai_gemm_bf16: operands must be 16-byte aligned");
     if (d->a_kmajor) APTAI_REQUIRE(d->M % 8 == 0 && d->M >= 8, "aptai_gemm_bf16: K-major A needs M %% 8 == 0");
@@ -305,8 +328,8 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         for (int l = 0; l < 2; ++l) {
             g.sA[l] = d->batch_stride_a[l]; g.sB[l] = d->batch_stride_b[l]; g.sC[l] = d->batch_stride_c[l];
             g.sBias[l] = d->batch_stride_bias[l]; g.sR[l] = d->batch_stride_res[l]; g.sAux[l] = d->batch_stride_aux[l];
-            APTAI_REQUIRE(g.sA[l] % 8 == 0 && g.sB[l] % 8 == 0 && g.sC[l] % 4 == 0 && g.sBias[l] % 4 == 0 &&
-                              g.sR[l] % 4 == 0 && g.sAux[l] % 4 == 0,
+            APTAI_REQUIRE(g.sA[l] % 8 == 0 && g.sB[l] % 8 == 0 && g.sC[l] % 8 == 0 && g.sBias[l] % 4 == 0 &&
+                              g.sR[l] % 8 == 0 && g.sAux[l] % 8 == 0,
                           "aptai_gemm_bf16: batch strides must keep vector alignment");
         }
         APTAI_REQUIRE(nbatch <= 65535, "aptai_gemm_bf16: too many batches");

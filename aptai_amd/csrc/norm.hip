@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 o[r] = (v[j][r] - mu) * rs * gm[j][r] + bt[j][r];
-                if (gelu_after) o[r] = gelu_erf(o[r]);
+                if (gelu_after) o[r] = gelu_fast(o[r]);
             }
             *(u32x2*)(yr + (j * 64 + lane) * 4) = (u32x2){pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
         }
@@ -134,19 +134,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// out[which][col] = sum_b partials[b][which][col]
-__global__ void colsum_partials_kernel(const float* __restrict__ partials, float* __restrict__ out0,
-                                       float* __restrict__ out1, int nblocks, int cols) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * cols) return;
-    const int which = c / cols, col = c % cols;
+// out[which][col] = sum_b partials[b][which][col].  block = 64 columns x 4 slices of the block list, LDS combine.
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partials, float* __restrict__ out0,
+                                                              float* __restrict__ out1, int nblocks, int cols) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;              // index into the concatenated [2][cols] vector
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partials[((long)b * 2 + which) * cols + col];
-    float* o = which ? out1 : out0;
-    if (o) o[col] = s;
+    if (c < 2 * cols) {
+        const int which = c / cols, col = c % cols;
+        for (int b = slice; b < nblocks; b += 4) s += partials[((long)b * 2 + which) * cols + col];
+    }
+    red[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && c < 2 * cols) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        float* o = (c / cols) ? out1 : out0;
+        if (o) o[c % cols] = t;
+    }
 }
 
-constexpr int LN_BWD_MAX_BLOCKS = 512;
+constexpr int LN_BWD_MAX_BLOCKS = 256;
 
 }  // namespace
 
@@ -200,7 +208,7 @@ extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* m
     APTAI_CHECK_LAUNCH("ln_bwd_kernel");
     if (dgamma || dbeta) {
         const int n = 2 * (int)cols;
-        APTAI_LAUNCH(colsum_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+        APTAI_LAUNCH(colsum_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, stream,
                            (const float*)workspace, dgamma, dbeta, (int)blocks, (int)cols);
         APTAI_CHECK_LAUNCH("colsum_partials_kernel");
     }
