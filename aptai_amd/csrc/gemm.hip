@@ -13,6 +13,8 @@
 // per-lane SOURCE address and on the LDS read (LDS-DMA writes are lane-linear).  KC fragments are read with
 // ds_read_b128, KM fragments with ds_read_b64_tr_b16 (hardware transpose).  MFMA operands are swapped
 // (D = colfrag x rowfrag) so each lane ends up with 4 consecutive output columns -> 8/16-byte stores.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -273,6 +275,283 @@ int launch_gemm(const GemmArgs& g, int nbatch, int nsplit, hipStream_t stream) {
     return APTAI_OK;
 }
 
+
+// =====================================================================================================================
+// 256 x 256 x 64 tile, 512 threads = 8 waves (2 M-groups x 4 N-columns), one block per CU, 128 KiB of LDS.
+//
+// Schedule (after the "8-phase" idea of the CDNA4 playbook, re-derived for this kernel):
+//  * a K-tile is consumed in 4 PHASES, one 64x32 quadrant of the wave's 128x64 output per phase (16 MFMAs):
+//      p0: (qm0,qn0) reads A-half0 + B-half0 fragments   p1: (qm0,qn1) reads B-half1
+//      p2: (qm1,qn1) reads A-half1                        p3: (qm1,qn0) reads nothing (B-half0 kept in registers)
+//    so every 16-KiB half-tile {A0,B0,B1,A1} has a LAST ds_read phase (0,0,1,2) and is restaged by LDS-DMA exactly
+//    two or more phases later: half-tile h (stream order A0,B0,B1,A1 per K-tile) is issued in global phase h-6.
+//  * one half-tile (2 x global_load_lds_dwordx4 per thread) is issued per phase and FOUR half-tiles stay in
+//    flight: `s_waitcnt vmcnt(8)` per phase, never 0 in the main loop; raw s_barrier (no compiler vmcnt(0)).
+//  * the two waves of a SIMD belong to different M-groups, and group 1 runs one barrier behind group 0:
+//    while one wave of the SIMD issues its MFMA cluster the other issues ds_reads + LDS-DMA.
+//  Hazards: RAW - the wait that retires half-tile h sits in the phase BEFORE its first read, in front of a barrier
+//  every wave crosses; WAR - a region is restaged >= 2 phases after its last read (covers the group stagger).
+constexpr int T2_THREADS = 512;
+constexpr int T2_BM = 256, T2_BN = 256;
+constexpr int T2_HALF_BYTES = 128 * BK * 2;             // 16 KiB
+constexpr int T2_BUF_BYTES = 4 * T2_HALF_BYTES;         // A0 A1 B0 B1
+constexpr int T2_SMEM = 2 * T2_BUF_BYTES;               // 128 KiB
+constexpr int T2_EPI_PITCH = T2_BN * 4 + 16;            // fp32 row of 256 columns + pad
+static_assert(64 * T2_EPI_PITCH <= T2_SMEM, "epilogue pass must fit the staging LDS");
+
+template <bool KM>
+__device__ __forceinline__ void stage_half(const bf16_t* __restrict__ base, long ld, int row0, int rows_total, int k0,
+                                           char* lds_half, int tid, int wave_base_tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int cid = it * T2_THREADS + tid;
+        const bf16_t* src;
+        if (!KM) {
+            const int row = cid >> 3, pc = cid & 7;
+            int grow = row0 + row;
+            grow = grow < rows_total ? grow : rows_total - 1;
+            src = base + (long)grow * ld + k0 + ((pc ^ (row & 7)) << 3);
+        } else {
+            const int krow = cid >> 4, pc = cid & 15;
+            int col = row0 + ((pc ^ km_swz(krow)) << 3);
+            col = col <= rows_total - 8 ? col : rows_total - 8;
+            src = base + (long)(k0 + krow) * ld + col;
+        }
+        char* dst = lds_half + (it * T2_THREADS + wave_base_tid) * 16;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst), 16, 0, 0);
+    }
+}
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+__global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;            // waves w and w+4 share a SIMD and sit in different groups
+    const int wave_base_tid = wave * 64;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+    const int m0 = tile_m * T2_BM, n0 = tile_n * T2_BN;
+    if (gridDim.y > 1) {
+        const int bo = blockIdx.y / g.nb_inner, bi = blockIdx.y % g.nb_inner;
+        g.A += bo * g.sA[0] + bi * g.sA[1];
+        g.B += bo * g.sB[0] + bi * g.sB[1];
+        const long co = bo * g.sC[0] + bi * g.sC[1];
+        g.C = OUT_F32 ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
+        if (g.out_pre) g.out_pre += co;
+        if (g.bias) g.bias += bo * g.sBias[0] + bi * g.sBias[1];
+        if (g.residual) g.residual += bo * g.sR[0] + bi * g.sR[1];
+        if (g.aux) g.aux += bo * g.sAux[0] + bi * g.sAux[1];
+    }
+    const int split = blockIdx.z;
+    const int total_kt = g.K / BK;
+    const int kt_begin = split * g.ktiles_per_split;
+    int kt_end = kt_begin + g.ktiles_per_split;
+    kt_end = kt_end < total_kt ? kt_end : total_kt;
+    const int nk = kt_end - kt_begin;
+    const int total_h = 4 * nk;                         // half-tiles in stream order A0 B0 B1 A1 per K-tile
+
+    // issue half-tile h of the stream (uniform control flow)
+    auto stage = [&](int h) {
+        const int t = h >> 2, part = h & 3;
+        char* buf = smem + (t & 1) * T2_BUF_BYTES;
+        const int k0 = (kt_begin + t) * BK;
+        if (part == 0) stage_half<A_KM>(g.A, g.lda, m0, g.M, k0, buf, tid, wave_base_tid);
+        else if (part == 3) stage_half<A_KM>(g.A, g.lda, m0 + 128, g.M, k0, buf + T2_HALF_BYTES, tid, wave_base_tid);
+        else if (part == 1) stage_half<B_KM>(g.B, g.ldb, n0, g.N, k0, buf + 2 * T2_HALF_BYTES, tid, wave_base_tid);
+        else stage_half<B_KM>(g.B, g.ldb, n0 + 128, g.N, k0, buf + 3 * T2_HALF_BYTES, tid, wave_base_tid);
+    };
+
+    f32x4 acc[2][2][4][2];                              // [qm][qn][i][j]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: 6 half-tiles in flight, the first two retired
+#pragma unroll
+    for (int h = 0; h < 6; ++h)
+        if (h < total_h) stage(h);
+    if (total_h >= 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+
+    bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+    for (int t = 0; t < nk; ++t) {
+        const char* buf = smem + (t & 1) * T2_BUF_BYTES;
+        const char* sA0 = buf, *sA1 = buf + T2_HALF_BYTES, *sB0 = buf + 2 * T2_HALF_BYTES, *sB1 = buf + 3 * T2_HALF_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            // ---------------- load section: fragment reads of this phase, then the LDS-DMA of half-tile G+6
+            if (p == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) b0f[j][ks] = read_frag<B_KM>(sB0, wc * 32 + j * 16, ks, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) af[i][ks] = read_frag<A_KM>(sA0, wr * 64 + i * 16, ks, lane);
+            } else if (p == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) b1f[j][ks] = read_frag<B_KM>(sB1, wc * 32 + j * 16, ks, lane);
+            } else if (p == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) af[i][ks] = read_frag<A_KM>(sA1, wr * 64 + i * 16, ks, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int G = 4 * t + p;
+            const int hn = G + 6;
+            if (hn < total_h) {
+                stage(hn);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                const int allow = total_h - G - 3;      // half-tiles that may stay in flight (need h <= G+2 landed)
+                if (allow >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (allow == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (allow == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- MFMA section: one quadrant x K=64
+            __builtin_amdgcn_s_setprio(1);
+            constexpr int QM[4] = {0, 0, 1, 1}, QN[4] = {0, 1, 1, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bf16x8 bfrag = (QN[p] == 0) ? b0f[j][ks] : b1f[j][ks];
+                        acc[QM[p]][QN[p]][i][j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag, af[i][ks], acc[QM[p]][QN[p]][i][j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ------------------------------------------------------------------ epilogue: 4 passes of 64 rows x 256 cols
+    const int flags = g.flags;
+    const int cl = (tid & 31) * 8;
+    const int n = n0 + cl;
+    const bool n_ok = n < g.N;
+    float bias8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bias8[r] = 0.f;
+    if ((flags & APTAI_EPI_BIAS) && n_ok) {
+        const f32x4 bb0 = *(const f32x4*)(g.bias + n), bb1 = *(const f32x4*)(g.bias + n + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bias8[r] = bb0[r]; bias8[4 + r] = bb1[r]; }
+    }
+    const float alpha = (flags & APTAI_EPI_ALPHA) ? g.alpha : 1.0f;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int pqm = pass >> 1, pwr = pass & 1;      // rows m0 + pqm*128 + pwr*64 + [0,64)
+        if (wr == pwr) {
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ml = i * 16 + (lane & 15);
+                        const int nl = qn * 128 + wc * 32 + j * 16 + (lane >> 4) * 4;
+                        *(f32x4*)(smem + ml * T2_EPI_PITCH + nl * 4) = acc[pqm][qn][i][j];
+                    }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int it = 0; it < 4; ++it) {
+            const int ml = it * 16 + (tid >> 5);
+            const int m = m0 + pqm * 128 + pwr * 64 + ml;
+            if (m >= g.M || !n_ok) continue;
+            const f32x4 v0 = *(const f32x4*)(smem + ml * T2_EPI_PITCH + cl * 4);
+            const f32x4 v1 = *(const f32x4*)(smem + ml * T2_EPI_PITCH + cl * 4 + 16);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = fmaf(v[r], alpha, bias8[r]);
+            if (OUT_F32) {
+                float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
+                *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                continue;
+            }
+            if (g.out_pre)
+                *(u32x4*)(g.out_pre + (long)m * g.ldc + n) =
+                    (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            if (flags & APTAI_EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
+            }
+            if (flags & APTAI_EPI_DROPOUT) {
+                const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {
+                    const uint32_t hsh = drop_hash_pair(e + r, g.seed0, g.seed1);
+                    v[r] = (hsh & 0xffffu) >= g.thr16 ? v[r] * g.dscale : 0.f;
+                    v[r + 1] = (hsh >> 16) >= g.thr16 ? v[r + 1] * g.dscale : 0.f;
+                }
+            }
+            if (flags & APTAI_EPI_DGELU) {
+                const u32x4 a = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[2 * r] *= gelu_fast_grad(lo_bf(a[r]));
+                    v[2 * r + 1] *= gelu_fast_grad(hi_bf(a[r]));
+                }
+            }
+            if (flags & APTAI_EPI_RESIDUAL) {
+                const u32x4 a = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[2 * r] += lo_bf(a[r]); v[2 * r + 1] += hi_bf(a[r]); }
+            }
+            *(u32x4*)((bf16_t*)g.C + (long)m * g.ldc + n) =
+                (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        }
+        __syncthreads();
+    }
+}
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+int launch_gemm256(GemmArgs g, int nbatch, int nsplit, hipStream_t stream) {
+    auto kern = gemm256_kernel<A_KM, B_KM, OUT_F32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T2_SMEM);
+        attr_set = true;
+    }
+    g.tiles_m = (int)ceil_div(g.M, T2_BM);
+    g.tiles_n = (int)ceil_div(g.N, T2_BN);
+    dim3 grid(g.tiles_m * g.tiles_n, nbatch, nsplit);
+    APTAI_LAUNCH(kern, grid, dim3(T2_THREADS), T2_SMEM, stream, g);
+    APTAI_CHECK_LAUNCH("gemm256_kernel");
+    return APTAI_OK;
+}
+
 }  // namespace
 
 extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
@@ -345,7 +624,33 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         g.C = d->workspace;
         g.slab_stride = (long)d->M * d->N;
     }
+    // tile selection: the 256x256 deep-pipelined kernel when the grid still fills the chip, else 128x128 (2 blocks/CU)
+    int tile = d->tile;
+    if (tile == 0) {
+        static int env_tile = -1;
+        if (env_tile < 0) {
+            const char* e = getenv("APTAI_GEMM_TILE");
+            env_tile = e ? atoi(e) : 0;
+        }
+        tile = env_tile;
+    }
+    if (tile == 0) {
+        // wave-quantisation model fitted to tools/gemm_bench*.py on MI355X: the 256-tile kernel sustains ~1.25x the
+        // 128-tile kernel per busy CU (1 block/CU, 256 slots) but needs the grid to fill whole rounds of 256 tiles;
+        // the 128-tile kernel runs 2 blocks/CU (512 slots).
+        const long t256 = ceil_div(d->M, T2_BM) * ceil_div(d->N, T2_BN) * nbatch * nsplit;
+        const long t128 = ceil_div(d->M, BM) * ceil_div(d->N, BN) * nbatch * nsplit;
+        const double e256 = (double)t256 / (double)(ceil_div(t256, 256) * 256);
+        const double e128 = (double)t128 / (double)(ceil_div(t128, 512) * 512);
+        tile = (d->M >= 256 && d->N >= 256 && 1.25 * e256 > e128) ? 256 : 128;
+    }
     int rc;
+    if (tile == 256) {
+        if (!d->a_kmajor && !d->b_kmajor) rc = f32 ? launch_gemm256<false, false, true>(g, nbatch, nsplit, stream) : launch_gemm256<false, false, false>(g, nbatch, nsplit, stream);
+        else if (!d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm256<false, true, true>(g, nbatch, nsplit, stream) : launch_gemm256<false, true, false>(g, nbatch, nsplit, stream);
+        else if (d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm256<true, true, true>(g, nbatch, nsplit, stream) : launch_gemm256<true, true, false>(g, nbatch, nsplit, stream);
+        else APTAI_FAIL(APTAI_ERR_INVALID, "aptai_gemm_bf16: A K-major with B K-contiguous is not built");
+    } else
     if (!d->a_kmajor && !d->b_kmajor) rc = f32 ? launch_gemm<false, false, true>(g, nbatch, nsplit, stream) : launch_gemm<false, false, false>(g, nbatch, nsplit, stream);
     else if (!d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm<false, true, true>(g, nbatch, nsplit, stream) : launch_gemm<false, true, false>(g, nbatch, nsplit, stream);
     else if (d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm<true, true, true>(g, nbatch, nsplit, stream) : launch_gemm<true, true, false>(g, nbatch, nsplit, stream);

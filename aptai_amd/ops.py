@@ -26,7 +26,8 @@ class GemmDesc(ctypes.Structure):
                 ("split_k", c_int), ("accumulate", c_int), ("workspace", c_void_p), ("workspace_bytes", c_i64),
                 ("batch_outer", c_int), ("batch_inner", c_int),
                 ("batch_stride_a", c_i64 * 2), ("batch_stride_b", c_i64 * 2), ("batch_stride_c", c_i64 * 2),
-                ("batch_stride_bias", c_i64 * 2), ("batch_stride_res", c_i64 * 2), ("batch_stride_aux", c_i64 * 2)]
+                ("batch_stride_bias", c_i64 * 2), ("batch_stride_res", c_i64 * 2), ("batch_stride_aux", c_i64 * 2),
+                ("tile", c_int)]
 
 
 class GemmProbe:
@@ -69,7 +70,7 @@ def _dev(*ts) -> None:
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, ldb=None, out=None, ldc=None,
          a_kmajor=False, b_kmajor=False, out_f32=False, bias=None, gelu=False, residual=None, out_pre=None,
          dgelu_aux=None, alpha: Optional[float] = None, dropout_p: float = 0.0, seed: int = 0, split_k: int = 1,
-         accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None) -> torch.Tensor:
+         accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None, tile: int = 0) -> torch.Tensor:
     """C[M,N] = rowop(A)[M,K] . colop(B)[N,K]^T.  See aptai_gemm_bf16 in include/aptai_hip.h."""
     _dev(a, b, out, bias, residual, out_pre, dgelu_aux)
     if out is None:
@@ -102,6 +103,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
         d.dropout_p, d.seed = dropout_p, seed
     d.flags = flags
     d.split_k, d.accumulate = split_k, int(accumulate)
+    d.tile = tile
     if ldr is not None:
         d.ldr = ldr
     if batch is not None:

@@ -68,6 +68,7 @@ typedef struct {
     int batch_outer, batch_inner;
     int64_t batch_stride_a[2], batch_stride_b[2], batch_stride_c[2], batch_stride_bias[2], batch_stride_res[2],
         batch_stride_aux[2];
+    int tile;                       /* 0 = auto, 128 = 128x128 tile kernel, 256 = 256x256 deep-pipelined kernel */
 } aptai_gemm_desc;
 
 int aptai_gemm_bf16(const aptai_gemm_desc* desc, void* stream);
