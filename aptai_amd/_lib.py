@@ -27,8 +27,8 @@ ARGTYPES = {
     "aptai_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I, _P],
     "aptai_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _P, _P, _P, _I64, _I64, _P],
     "aptai_layernorm_bwd_workspace_bytes": [_I64, _I64],
-    "aptai_attention_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _U64, _P],
-    "aptai_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _U64, _I, _P],
+    "aptai_attention_fwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _U64, _P],
+    "aptai_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _U64, _I, _P],
     "aptai_cast_f32_to_bf16": [_P, _P, _I64, _I64, _I64, _P],
     "aptai_conv_weight_to_bf16": [_P, _P, _I64, _I64, _I64, _P],
     "aptai_posconv_weight": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
@@ -48,6 +48,9 @@ ARGTYPES = {
     "aptai_aptai_loss_bwd": [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _F, _F, _P, _P, _P, _P, _I64, _P],
     "aptai_aptai_loss_workspace_bytes": [],
     "aptai_gemm_workspace_bytes": [_I64, _I64, _I],
+    "aptai_ctc_fwd": [_P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _P, _P],
+    "aptai_ctc_bwd": [_P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _F, _P, _I64, _I, _P],
+    "aptai_ctc_workspace_bytes": [_I64, _I64, _I64],
     "aptai_device_check": [ctypes.c_char_p, _I],
 }
 

@@ -27,6 +27,7 @@ struct AttnArgs {
     const int* lens;
     bf16_t* ctx; long ldo;          // H
     float* lse2;
+    float* o32;                     // optional fp32 copy of the context (keeps delta = rowsum(dO*O) accurate)
     int B, Tp, H, heads;
     float c;                        // softmax_scale * log2(e)
     float scale;
@@ -190,14 +191,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             u32x2 o = {pack2bf(oT[dt][4 * g4 + 0] * inv, oT[dt][4 * g4 + 1] * inv),
                        pack2bf(oT[dt][4 * g4 + 2] * inv, oT[dt][4 * g4 + 3] * inv)};
             *(u32x2*)(og + d) = o;
+            if (a.o32)
+                *(f32x4*)(a.o32 + (rowbase + q) * a.ldo + hd * HD + d) =
+                    (f32x4){oT[dt][4 * g4 + 0] * inv, oT[dt][4 * g4 + 1] * inv, oT[dt][4 * g4 + 2] * inv, oT[dt][4 * g4 + 3] * inv};
         }
     if (a.lse2 && h == 0) a.lse2[((long)b * a.heads + hd) * a.Tp + q] = m_run + log2f(l_tot);
 }
 
 // ================================================================================== delta = rowsum(dO * O)
 // one wave per (row, head): 64 elements
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx, float* __restrict__ delta,
-                                  int B, int Tp, int H, int heads) {
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx, const float* __restrict__ o32,
+                                  float* __restrict__ delta, int B, int Tp, int H, int heads) {
     const long gw = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     const long total = (long)B * Tp * heads;
@@ -205,7 +209,7 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t*
     const long row = gw / heads;
     const int hd = (int)(gw % heads);
     const long off = row * H + hd * HD + lane;
-    float v = bf2f(dctx[off]) * bf2f(ctx[off]);
+    float v = bf2f(dctx[off]) * (o32 ? o32[off] : bf2f(ctx[off]));
     v = wave_sum(v);
     if (lane == 0) {
         const long bb = row / Tp, q = row % Tp;
@@ -419,20 +423,21 @@ int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens
 
 }  // namespace
 
-extern "C" int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* ctx, float* lse2, int64_t B, int64_t Tp,
-                                   int64_t H, int64_t heads, float scale, float dropout_p, uint64_t seed, void* stream_) {
+extern "C" int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* ctx, float* lse2, float* ctx_f32, int64_t B,
+                                   int64_t Tp, int64_t H, int64_t heads, float scale, float dropout_p, uint64_t seed,
+                                   void* stream_) {
     AttnArgs a;
     int rc = fill_args(a, "aptai_attention_fwd", qkv, lens, B, Tp, H, heads, scale, dropout_p, seed);
     if (rc) return rc;
     APTAI_REQUIRE(ctx != nullptr, "aptai_attention_fwd: null ctx");
-    a.ctx = (bf16_t*)ctx; a.lse2 = lse2;
+    a.ctx = (bf16_t*)ctx; a.lse2 = lse2; a.o32 = ctx_f32;
     APTAI_LAUNCH(attn_fwd_kernel, dim3((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream_, a);
     APTAI_CHECK_LAUNCH("attn_fwd_kernel");
     return APTAI_OK;
 }
 
-extern "C" int aptai_attention_bwd(const void* qkv, const int32_t* lens, const void* ctx, const void* dctx,
+extern "C" int aptai_attention_bwd(const void* qkv, const int32_t* lens, const void* ctx, const float* ctx_f32, const void* dctx,
                                    const float* lse2, float* delta_ws, void* dqkv, int64_t B, int64_t Tp, int64_t H,
                                    int64_t heads, float scale, float dropout_p, uint64_t seed, int dctx_zero_beyond_len, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -444,7 +449,7 @@ extern "C" int aptai_attention_bwd(const void* qkv, const int32_t* lens, const v
     a.skip_pad_q = dctx_zero_beyond_len;
     const long waves = (long)B * Tp * heads;
     APTAI_LAUNCH(attn_delta_kernel, dim3((unsigned)ceil_div(waves * 64, 256)), dim3(256), 0, stream,
-                       (const bf16_t*)dctx, (const bf16_t*)ctx, delta_ws, (int)B, (int)Tp, (int)H, (int)heads);
+                       (const bf16_t*)dctx, (const bf16_t*)ctx, ctx_f32, delta_ws, (int)B, (int)Tp, (int)H, (int)heads);
     APTAI_CHECK_LAUNCH("attn_delta_kernel");
     dim3 grid((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B);
     APTAI_LAUNCH(attn_bwd_dkdv_kernel, grid, dim3(256), 0, stream, a);

@@ -171,16 +171,19 @@ def attention_fwd(qkv, lens_i32, B, Tp, H, heads, *, dropout_p=0.0, seed=0, save
     _dev(qkv, lens_i32)
     ctx = torch.empty((B * Tp, H), device=qkv.device, dtype=torch.bfloat16)
     lse2 = torch.empty((B, heads, Tp), device=qkv.device, dtype=torch.float32) if save_lse else None
-    _lib.call("aptai_attention_fwd", qkv.data_ptr(), lens_i32.data_ptr(), ctx.data_ptr(), _ptr(lse2), B, Tp, H, heads,
-              (H // heads) ** -0.5, dropout_p, seed, _stream())
-    return ctx, lse2
+    ctx32 = torch.empty((B * Tp, H), device=qkv.device, dtype=torch.float32) if save_lse else None
+    _lib.call("aptai_attention_fwd", qkv.data_ptr(), lens_i32.data_ptr(), ctx.data_ptr(), _ptr(lse2), _ptr(ctx32), B, Tp, H,
+              heads, (H // heads) ** -0.5, dropout_p, seed, _stream())
+    return ctx, (lse2, ctx32) if save_lse else None
 
 
-def attention_bwd(qkv, lens_i32, ctx, dctx, lse2, B, Tp, H, heads, *, dropout_p=0.0, seed=0, dctx_zero_beyond_len=False):
+def attention_bwd(qkv, lens_i32, ctx, dctx, stats, B, Tp, H, heads, *, dropout_p=0.0, seed=0, dctx_zero_beyond_len=False):
+    """``stats`` = the (lse2, ctx_f32) pair returned by attention_fwd."""
+    lse2, ctx32 = stats
     _dev(qkv, lens_i32, ctx, dctx, lse2)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, heads, Tp), device=qkv.device, dtype=torch.float32)
-    _lib.call("aptai_attention_bwd", qkv.data_ptr(), lens_i32.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse2.data_ptr(),
+    _lib.call("aptai_attention_bwd", qkv.data_ptr(), lens_i32.data_ptr(), ctx.data_ptr(), _ptr(ctx32), dctx.data_ptr(), lse2.data_ptr(),
               delta.data_ptr(), dqkv.data_ptr(), B, Tp, H, heads, (H // heads) ** -0.5, dropout_p, seed,
               int(dctx_zero_beyond_len), _stream())
     return dqkv
@@ -308,3 +311,34 @@ def aptai_loss_bwd(tv_pred, tv_tgt, logits, ldl, rows_per_b, phn_tgt, B, T, n_tv
               phn_tgt.data_ptr(), B, T, n_tv, n_phn, w_mse, w_ce, scalars.data_ptr(), _ptr(grad_out), d_tv.data_ptr(),
               d_logits.data_ptr(), ldd, _stream())
     return d_tv, d_logits
+
+
+# ----------------------------------------------------------------------------- CTC
+_REDUCTION = {"none": 0, "mean": 1, "sum": 2}
+
+
+def ctc_fwd(logits, ldl, rows_per_b, targets_i32, input_lens_i32, target_lens_i32, B, T, V, *, blank=0, reduction="mean",
+            zero_infinity=True, vocab_sizes_i32=None, want_log_probs=True):
+    """Returns (loss scalar tensor, nll [B], log_probs (T,B,V) | None, alpha workspace)."""
+    _dev(logits, targets_i32, input_lens_i32, target_lens_i32, vocab_sizes_i32)
+    dev = logits.device
+    ldt = targets_i32.shape[1]
+    alpha = torch.empty(_lib.lib().aptai_ctc_workspace_bytes(B, T, ldt) // 4, device=dev, dtype=torch.float32)
+    nll = torch.empty(B, device=dev, dtype=torch.float32)
+    loss = torch.zeros(1, device=dev, dtype=torch.float32)
+    lp = torch.empty((T, B, V), device=dev, dtype=torch.float32) if want_log_probs else None
+    _lib.call("aptai_ctc_fwd", logits.data_ptr(), ldl, rows_per_b, targets_i32.data_ptr(), ldt, input_lens_i32.data_ptr(),
+              target_lens_i32.data_ptr(), _ptr(vocab_sizes_i32), B, T, V, blank, _REDUCTION[reduction], int(zero_infinity),
+              _ptr(lp), alpha.data_ptr(), nll.data_ptr(), loss.data_ptr(), _stream())
+    return loss, nll, lp, alpha
+
+
+def ctc_bwd(logits, ldl, rows_per_b, targets_i32, input_lens_i32, target_lens_i32, B, T, V, alpha, nll, grad_out, *, blank=0,
+            reduction="mean", zero_infinity=True, vocab_sizes_i32=None, ldd=64, out_dtype=torch.bfloat16, extra_scale=1.0):
+    _dev(logits, targets_i32, alpha, nll, grad_out)
+    d = torch.empty((B * rows_per_b, ldd), device=logits.device, dtype=out_dtype)
+    _lib.call("aptai_ctc_bwd", logits.data_ptr(), ldl, rows_per_b, targets_i32.data_ptr(), targets_i32.shape[1],
+              input_lens_i32.data_ptr(), target_lens_i32.data_ptr(), _ptr(vocab_sizes_i32), B, T, V, blank, _REDUCTION[reduction],
+              int(zero_infinity), alpha.data_ptr(), nll.data_ptr(), _ptr(grad_out), extra_scale, d.data_ptr(), ldd,
+              int(out_dtype == torch.bfloat16), _stream())
+    return d

@@ -1,0 +1,175 @@
+"""``Wav2Vec2_PR`` — drop-in for the reference's CTC phoneme recogniser (models/w2v2_pr.py:18-291) on MI355X.
+
+Same constructor ``(pretrain_cfg, cache_dir, huggingface_model_id, vocab)``, ``forward(input_values, input_lengths,
+phoneme_labels)`` dict, inference helpers and state-dict keys (``wav2vec2.*``, ``pr_head.*``).  The torchaudio /
+flashlight beam-search decoder the reference calls (models/w2v2_pr.py:143-159) is not in the image: decoding here is
+the best path (frame argmax on the device, collapse + blank removal on the host) — *parity unpinned* (SURVEY.md §8c).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hostlogic, ops
+from .wav2vec2 import Wav2Vec2Model, _round_up, _seed
+
+
+class _CtcHeadFn(torch.autograd.Function):
+    """dropout -> Linear(H, V) -> log_softmax -> CTC (models/w2v2_pr.py:54-81) with the fused CTC gradient."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, st):
+        g, M, H = st.g, st.g.M, h.shape[1]
+        dev = h.device
+        V = w.shape[0]
+        Np = _round_up(V, 64)
+        hd = ops.dropout(h, st.p_final, st.seed) if st.p_final > 0 else h
+        wp = torch.zeros((Np, H), device=dev, dtype=torch.bfloat16)
+        ops.cast_bf16(w.detach(), wp[:V])
+        bp = torch.zeros(Np, device=dev, dtype=torch.float32)
+        bp[:V] = b.detach()
+        logits = ops.gemm(hd, wp, M, Np, H, bias=bp, out_f32=True)
+        loss, nll, lp, alpha = ops.ctc_fwd(logits, Np, g.Tp, st.targets, st.state_lens, st.target_lens, g.B, g.T, V,
+                                           blank=st.blank, reduction=st.reduction, zero_infinity=st.zero_infinity)
+        ctx.st = st
+        ctx.saved = SimpleNamespace(hd=hd, wp=wp, logits=logits, alpha=alpha, nll=nll, V=V, Np=Np)
+        ctx.mark_non_differentiable(logits, lp, hd)
+        return loss.reshape(()), logits, lp, hd
+
+    @staticmethod
+    def backward(ctx, gloss, *_):
+        st, s = ctx.st, ctx.saved
+        g, M, H = st.g, st.g.M, s.hd.shape[1]
+        gl = gloss.float().reshape(1).contiguous()
+        dlog = ops.ctc_bwd(s.logits, s.Np, g.Tp, st.targets, st.state_lens, st.target_lens, g.B, g.T, s.V, s.alpha, s.nll, gl,
+                           blank=st.blank, reduction=st.reduction, zero_infinity=st.zero_infinity, ldd=s.Np)
+        dh = ops.gemm(dlog, s.wp, M, H, s.Np, b_kmajor=True)
+        sk = max(1, min(16, M // 1024))
+        dw = ops.gemm(dlog, s.hd, s.Np, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk)
+        db = ops.colsum(dlog, M, s.Np)
+        if st.p_final > 0:
+            dh = ops.dropout(dh, st.p_final, st.seed)
+        ctx.saved = None
+        return dh, dw[:s.V], db[:s.V], None
+
+
+class Wav2Vec2_PR(nn.Module):
+    """Wav2Vec2 model used as a phoneme recognizer."""
+
+    def __init__(self, pretrain_cfg, cache_dir, huggingface_model_id, vocab):
+        super().__init__()
+        self.cache_dir = cache_dir
+        self.huggingface_model_id = huggingface_model_id
+        self.pretrain_cfg = pretrain_cfg
+        self.wav2vec2 = Wav2Vec2Model.from_pretrained(huggingface_model_id, config=pretrain_cfg, cache_dir=cache_dir)
+        self.wav2vec2.gradient_checkpointing_enable()
+        cfg = self.wav2vec2.config
+        self.dropout = nn.Dropout(cfg.final_dropout)
+        self.pr_head = nn.Linear(cfg.hidden_size, cfg.vocab_size)
+        self.vocab = vocab
+
+    # ------------------------------------------------------------------ training forward (models/w2v2_pr.py:40-88)
+    def forward(self, input_values, input_lengths, phoneme_labels):
+        cfg = self.wav2vec2.config
+        outputs = self.wav2vec2(input_values, attention_mask=input_lengths[:, None], return_dict=True, output_hidden_states=True)
+        g = outputs._geom
+        dev = outputs._flat_last.device
+        state_lens = self.wav2vec2._get_feat_extract_output_lengths(input_lengths)
+        target_lengths = hostlogic.ctc_target_lengths(phoneme_labels)          # count of labels >= 0 (:62-70)
+        st = SimpleNamespace(g=g, p_final=self.dropout.p if self.training else 0.0,
+                             seed=_seed(self.wav2vec2.base_seed, self.wav2vec2._step, 777),
+                             targets=phoneme_labels.to(dev).to(torch.int32).contiguous(),
+                             state_lens=state_lens.to(dev).to(torch.int32).contiguous(),
+                             target_lens=target_lengths.to(dev).to(torch.int32).contiguous(), blank=getattr(cfg, "blank", 0),
+                             reduction=cfg.ctc_loss_reduction, zero_infinity=cfg.ctc_zero_infinity)
+        loss, logits, log_probs, hd = _CtcHeadFn.apply(outputs._flat_last, self.pr_head.weight, self.pr_head.bias, st)
+        V = self.pr_head.weight.shape[0]
+        return {'loss': loss, 'phoneme_logits': logits.view(g.B, g.Tp, -1)[:, :g.T, :V], 'log_probs': log_probs,
+                'hidden_states': hd.view(g.B, g.Tp, -1)[:, :g.T]}
+
+    # ------------------------------------------------------------------ inference helpers
+    def _logits_eval(self, audio_inputs, lengths_2d):
+        """eval-mode encoder + pr_head (fp32 logits (B,T,V)); shared by every helper below."""
+        out = self.wav2vec2(audio_inputs, attention_mask=lengths_2d, return_dict=True, output_hidden_states=True)
+        g, h = out._geom, out._flat_last
+        V, H = self.pr_head.weight.shape
+        Np = _round_up(V, 64)
+        wp = torch.zeros((Np, H), device=h.device, dtype=torch.bfloat16)
+        ops.cast_bf16(self.pr_head.weight.detach(), wp[:V])
+        bp = torch.zeros(Np, device=h.device, dtype=torch.float32)
+        bp[:V] = self.pr_head.bias.detach()
+        logits = ops.gemm(h, wp, g.M, Np, H, bias=bp, out_f32=True).view(g.B, g.Tp, Np)[:, :g.T, :V]
+        return out, logits
+
+    def _decode(self, logits):
+        """Best-path decode of every utterance over ALL frames of the padded batch, like the reference's decoder call
+        (models/w2v2_pr.py:155 passes no lengths).  argmax runs on the device; ONE host transfer for the batch."""
+        blank = int(self.vocab.get('(blank)', 0)) if isinstance(self.vocab, dict) else 0
+        ids = logits.argmax(dim=-1).cpu().numpy()
+        out = []
+        for row in ids:
+            keep = np.ones(len(row), dtype=bool)
+            keep[1:] = row[1:] != row[:-1]
+            r = row[keep]
+            out.append(r[r != blank].astype(np.int64))
+        return out
+
+    def get_embeddings(self, audio_inputs, audio_lengths):
+        """models/w2v2_pr.py:124-167 (the encoder runs ONCE: the reference's extra feature_extractor pass :129 only
+        produced 'features_hidden', which no caller reads; it is returned as None)."""
+        self.eval()
+        with torch.no_grad():
+            out, logits = self._logits_eval(audio_inputs, audio_lengths[:, None] if audio_lengths.dim() == 1 else audio_lengths)
+            frame_seq_lens = self.wav2vec2._get_feat_extract_output_lengths(audio_lengths)
+            return {'features_hidden': None, 'last_transf_hidden': out.last_hidden_state.permute(0, 2, 1),
+                    'phoneme_logits': logits.cpu().numpy().transpose(0, 2, 1), 'phn_pred_seq_idx': self._decode(logits),
+                    'frame_seq_lens': frame_seq_lens.cpu().numpy(), '_out': out}
+
+    def _wav(self, wav):
+        device = next(self.parameters()).device
+        if type(wav) is torch.Tensor:
+            wav = wav[0]
+        wav_input = torch.unsqueeze(torch.Tensor(wav), dim=0).to(device)
+        wav_len = torch.unsqueeze(torch.LongTensor([len(wav)]), dim=0).to(device)
+        return wav, wav_input, wav_len
+
+    def get_ctc_logits(self, wav):
+        self.eval()
+        with torch.no_grad():
+            _, wav_input, wav_len = self._wav(wav)
+            _, logits = self._logits_eval(wav_input, wav_len)
+            return logits.squeeze(dim=0).cpu().numpy()
+
+    def pred_phn_seq(self, wav, vocab):
+        self.eval()
+        with torch.no_grad():
+            _, wav_input, wav_len = self._wav(wav)
+            _, logits = self._logits_eval(wav_input, wav_len)
+            idx = self._decode(logits)[0]
+            inv = {v: k for k, v in vocab.items()}
+            return {'phn_seq_idx': idx, 'phn_seq_ipa': [inv.get(int(i), '?') for i in idx]}
+
+    def predict_phonemes_durations(self, wav, vocab):
+        """models/w2v2_pr.py:191-235; timesteps = first frame of each emitted (non-blank, de-duplicated) label."""
+        self.eval()
+        with torch.no_grad():
+            wav, wav_input, wav_len = self._wav(wav)
+            _, logits = self._logits_eval(wav_input, wav_len)
+            ids = logits[0].argmax(dim=-1).cpu().numpy()
+            frame_sec_ratio = len(wav) / logits.size(1) / 16000
+            keep = np.ones(len(ids), dtype=bool)
+            keep[1:] = ids[1:] != ids[:-1]
+            ts = np.nonzero(keep & (ids != 0))[0]
+            idx = ids[ts]
+            inv = {v: k for k, v in vocab.items()}
+            return {'phn_seq_idx': idx, 'phn_seq_ipa': [inv.get(int(i), '?') for i in idx],
+                    'phn_seq_dur': [t * frame_sec_ratio for t in ts]}
+
+    def get_config(self):
+        return {'huggingface_model_id': self.huggingface_model_id, 'cache_dir': self.cache_dir, 'pretrain_cfg': self.pretrain_cfg}
+
+    def freeze_feature_encoder(self):
+        self.wav2vec2.freeze_feature_encoder()

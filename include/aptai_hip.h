@@ -91,13 +91,15 @@ int64_t aptai_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
  * softmax(Q K^T * scale + key-padding mask) V per head (head_dim 64), flash-style, replacing HF:452-461 / sdpa
  * as called from HF:522-546, and its backward.  qkv [B*Tp][3H] bf16; lens int32 [B] valid frames (keys beyond are
  * masked, HF:678-688); Tp % 128 == 0; ctx [B*Tp][H] bf16; lse2 fp32 [B][heads][Tp] (log2-domain log-sum-exp).
- * dropout_p: attention-probability dropout (HF:458), mask from (seed, (b,h,q,k)). */
-int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* ctx, float* lse2, int64_t B, int64_t Tp, int64_t H,
-                        int64_t heads, float scale, float dropout_p, uint64_t seed, void* stream);
+ * dropout_p: attention-probability dropout (HF:458), mask from (seed, (b,h,q,k)).
+ * ctx_f32 (optional, [B*Tp][H] fp32): unrounded context; the backward's delta = rowsum(dO*O) is a small-difference term
+ * (dS = P*(dP - delta)) whose bf16 rounding would otherwise dominate the q/k gradients when attention is diffuse. */
+int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* ctx, float* lse2, float* ctx_f32, int64_t B, int64_t Tp,
+                        int64_t H, int64_t heads, float scale, float dropout_p, uint64_t seed, void* stream);
 /* delta_ws: fp32 [B][heads][Tp] scratch.  dctx_zero_beyond_len=1 lets the kernel skip query rows >= lens[b]
  * (their incoming gradient is exactly zero in the models: no loss term touches padded frames). */
-int aptai_attention_bwd(const void* qkv, const int32_t* lens, const void* ctx, const void* dctx, const float* lse2,
-                        float* delta_ws, void* dqkv, int64_t B, int64_t Tp, int64_t H, int64_t heads, float scale,
+int aptai_attention_bwd(const void* qkv, const int32_t* lens, const void* ctx, const float* ctx_f32, const void* dctx,
+                        const float* lse2, float* delta_ws, void* dqkv, int64_t B, int64_t Tp, int64_t H, int64_t heads, float scale,
                         float dropout_p, uint64_t seed, int dctx_zero_beyond_len, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ parameter prep
@@ -162,6 +164,25 @@ int aptai_aptai_loss_bwd(const float* tv_pred, const float* tv_tgt, const float*
                          const float* scalars, const float* grad_out, float* d_tv, void* d_logits_bf16, int64_t ldd,
                          void* stream);
 int64_t aptai_aptai_loss_workspace_bytes(void);
+
+/* ------------------------------------------------------------------------------------------------ CTC
+ * log_softmax + CTC negative log-likelihood (alpha recursion) and its gradient w.r.t. the LOGITS (beta recursion),
+ * replacing nn.functional.log_softmax + F.ctc_loss at models/w2v2_pr.py:59,73-81 and the per-sample nn.CTCLoss loop
+ * of ForwardSumLoss (models/modules.py:99-116; vocab_sizes[b] = N_b + 1 classes, targets 1..N_b).
+ * logits fp32 rows (b*rows_per_b + t) stride ldl; targets int32 [B][ldt] (any padding beyond target_lens[b]);
+ * reduction 0 none / 1 mean (mean_b nll_b / max(len_b,1)) / 2 sum; nll fp32 [B]; loss fp32 scalar;
+ * log_probs_out fp32 (T,B,V) or null; alpha_ws fp32 [B][T][2*ldt+1] kept for the backward. */
+int aptai_ctc_fwd(const float* logits, int64_t ldl, int64_t rows_per_b, const int32_t* targets, int64_t ldt,
+                  const int32_t* input_lens, const int32_t* target_lens, const int32_t* vocab_sizes, int64_t B, int64_t T,
+                  int64_t V, int blank, int reduction, int zero_infinity, float* log_probs_out, float* alpha_ws, float* nll,
+                  float* loss, void* stream);
+/* dlogits rows (b*rows_per_b + t) stride ldd, bf16 or fp32, zero outside t < input_lens[b] and v < V;
+ * gradient = grad_out[0] (device scalar, may be null = 1) * extra_scale * d loss / d logits. */
+int aptai_ctc_bwd(const float* logits, int64_t ldl, int64_t rows_per_b, const int32_t* targets, int64_t ldt,
+                  const int32_t* input_lens, const int32_t* target_lens, const int32_t* vocab_sizes, int64_t B, int64_t T,
+                  int64_t V, int blank, int reduction, int zero_infinity, const float* alpha_ws, const float* nll,
+                  const float* grad_out, float extra_scale, void* dlogits, int64_t ldd, int out_bf16, void* stream);
+int64_t aptai_ctc_workspace_bytes(int64_t B, int64_t T, int64_t ldt);
 
 #ifdef __cplusplus
 }
