@@ -1,0 +1,84 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient path (aptai_amd/dp.py) — averaged DP gradients of the
+sharded batch equal the single-process gradients of the whole batch, with incomplete buckets (LayerDrop'd parameters
+that received no gradient) and a bf16 communication dtype."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(),
+                               torch.nn.Linear(32, 4))
+
+
+def _worker(rank, world, port, comm_bf16, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aptai_amd.dp import GradBucketReducer, shard_batch
+    model = _model()
+    g = torch.Generator().manual_seed(1)
+    batch = {"x": torch.randn(8, 16, generator=g), "y": torch.randn(8, 4, generator=g)}
+    mine = shard_batch(batch, rank, world)
+    red = GradBucketReducer(model.parameters(), bucket_mb=0.002, comm_dtype=torch.bfloat16 if comm_bf16 else None)
+    assert len(red.buckets) >= 2
+    for step in range(2):                                   # two steps: buckets reset correctly
+        model.zero_grad(set_to_none=True)
+        h = model[1](model[0](mine["x"]))
+        if step == 1:
+            out = model[4](h)                               # "LayerDrop": skip model[2] -> its params get no grad
+        else:
+            out = model[4](model[3](model[2](h)))
+        # per-rank SUM scaled by the GLOBAL count, so the all-reduce AVERAGE times world == global-mean gradient
+        loss = ((out - mine["y"]) ** 2).sum() / (batch["x"].shape[0] * 4) * world
+        loss.backward()
+        red.finish()
+    q.put((rank, {n: p.grad.numpy().copy() for n, p in model.named_parameters()}))      # by value: the sender may exit first
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm_bf16", [False, True])
+def test_dp_gradients_equal_single_process(comm_bf16):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, comm_bf16, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _model()
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(8, 16, generator=g), torch.randn(8, 4, generator=g)
+    out = model[4](model[1](model[0](x)))                   # step-1 graph (model[2] skipped)
+    (((out - y) ** 2).sum() / (8 * 4)).backward()
+    tol = 2e-2 if comm_bf16 else 1e-6
+    for n, p in model.named_parameters():
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        for r in range(world):
+            got = torch.from_numpy(res[r][n])
+            assert (got - ref).abs().max().item() <= tol * (ref.abs().max().item() + 1e-6) + 1e-7, (n, r)
+    for n in res[0]:
+        assert (res[0][n] == res[1][n]).all()            # replicas stay bit-identical
+
+
+def test_shard_batch_is_contiguous():
+    from aptai_amd.dp import shard_batch
+    b = {"a": torch.arange(8), "b": torch.arange(16).view(8, 2)}
+    assert shard_batch(b, 1, 4)["a"].tolist() == [2, 3] and shard_batch(b, 3, 4)["b"].tolist() == [[12, 13], [14, 15]]

@@ -1,0 +1,140 @@
+"""CPU: host-side logic (integer frame arithmetic, SpecAugment sampler, LR schedule, collate), module surface
+(state-dict keys/shapes identical to the reference's), the C-ABI library (loads, exports every declared symbol;
+no compute without a GPU) and the no-fallback rule."""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from aptai_amd import hostlogic
+from aptai_amd.config import W2V2Config
+
+
+def test_frame_lengths_match_hf_golden_and_known_values():
+    z, _ = load_golden("ops_small")
+    cfg = W2V2Config()
+    got = hostlogic.feat_extract_output_lengths(torch.from_numpy(z["lens/in"]), cfg.conv_kernel, cfg.conv_stride)
+    assert got.dtype == torch.int64 and (got.numpy() == z["lens/out"]).all()
+    # SURVEY §2.4 probe values
+    for s, t in ((64000, 199), (160000, 499), (480000, 1499)):
+        assert hostlogic.feat_extract_output_lengths(s, cfg.conv_kernel, cfg.conv_stride) == t
+    assert hostlogic.conv_layer_lengths(160000, cfg.conv_kernel, cfg.conv_stride) == [31999, 15999, 7999, 3999, 1999, 999, 499]
+    assert (hostlogic.feat_extract_output_lengths(np.array([160000, 400]), cfg.conv_kernel, cfg.conv_stride) == [499, 1]).all()
+
+
+def test_frame_mask():
+    m = hostlogic.frame_attention_mask(5, torch.tensor([5, 2, 0]))
+    assert m.tolist() == [[True] * 5, [True, True, False, False, False], [False] * 5]
+
+
+def test_lr_schedule_matches_reference_formula():
+    f = hostlogic.get_lr_schedule(2, 8, 0.96)          # train/start_train_aptai.sh values
+    assert [f(e) for e in range(3)] == [5.0, 10.0, 10.0]
+    assert f(9) == 10.0 and abs(f(10) - 10.0) < 1e-12 and abs(f(12) - 10 * 0.96 ** 2) < 1e-12
+
+
+def test_collate_pads_like_the_reference():
+    rng = np.random.RandomState(0)
+    items = []
+    for n, t in ((1000, 3), (700, 2)):
+        items.append({"audio": torch.randn(n), "audio_len": n, "phn_frames_49hz": list(range(1, t + 1)),
+                      "phoneme_label": [3, 4][:t - 1], "tvs_norm_49hz": {k: rng.randn(t) for k in hostlogic.TV_NAMES}})
+    b = hostlogic.collate_aptai(items, with_phoneme_labels=True)
+    assert b["audio_inputs"].shape == (2, 1000) and float(b["audio_inputs"][1, 700:].abs().sum()) == 0.0
+    assert b["audio_lengths"].tolist() == [1000, 700] and b["audio_lengths"].dtype == torch.int64
+    assert b["phn_frames_49hz"].tolist() == [[1, 2, 3], [1, 2, 0]]
+    assert b["LA"].dtype == torch.float64 and b["LA"][1, 2].item() == -100.0
+    assert b["phoneme_labels"].dtype == torch.int32 and b["phoneme_labels"].tolist() == [[3, 4], [3, -100]]
+    p = hostlogic.collate_pr(items)
+    assert set(p) == {"input_values", "input_lengths", "phoneme_labels"}
+    assert hostlogic.ctc_target_lengths(p["phoneme_labels"]).tolist() == [2, 1]
+
+
+def test_lowpass_taps_probe_values():
+    h = hostlogic.lowpass_taps(10, 49)
+    assert len(h) == 51 and h[0] == 0.0 and abs(h[1] - (-3.127e-5)) < 1e-7 and abs(h[25] - 0.408130) < 1e-6
+    assert abs(h.sum() - 1.0) < 1e-12 and np.allclose(h, h[::-1])
+    z, _ = load_golden("ops_small")
+    assert np.array_equal(h, z["lowpass/taps"].reshape(-1))
+
+
+def test_best_path_decode():
+    logits = np.full((8, 4), -5.0)
+    for t, k in enumerate([0, 2, 2, 0, 2, 3, 3, 0]):
+        logits[t, k] = 1.0
+    assert hostlogic.ctc_best_path(logits, 8).tolist() == [2, 2, 3]
+    assert hostlogic.ctc_best_path(logits, 3).tolist() == [2]
+
+
+@pytest.mark.parametrize("kind", ["base", "large"])
+def test_state_dict_keys_match_reference_layout(kind):
+    """Keys and shapes equal the HF/reference layout (oracle.synth tables were checked against the reference's own
+    load_state_dict when the golden vectors were generated)."""
+    from oracle import synth
+    from aptai_amd.wav2vec2 import Wav2Vec2Model
+    cfg = (W2V2Config.base if kind == "base" else W2V2Config.large)(num_hidden_layers=2)
+    m = Wav2Vec2Model(cfg)
+    want = synth.w2v2_param_shapes(cfg, "")
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == dict(want)
+    m.freeze_feature_encoder()
+    assert all(not p.requires_grad for n, p in m.named_parameters() if n.startswith("feature_extractor"))
+    assert all(p.requires_grad for n, p in m.named_parameters() if not n.startswith("feature_extractor"))
+
+
+def test_from_pretrained_roundtrip_and_model_surfaces():
+    from oracle import synth
+    from aptai_amd.aptai import APTAI
+    from aptai_amd.w2v2_pr import Wav2Vec2_PR
+    from aptai_amd.wav2vec2 import Wav2Vec2Model
+    cfg = W2V2Config.large(num_hidden_layers=1, vocab_size=40)
+    with tempfile.TemporaryDirectory() as tmp:
+        src = Wav2Vec2Model(cfg)
+        src.save_pretrained(tmp)
+        assert json.load(open(os.path.join(tmp, "config.json")))["hidden_size"] == 1024
+        again = Wav2Vec2Model.from_pretrained(tmp)
+        for (k, a), (_, b) in zip(src.state_dict().items(), again.state_dict().items()):
+            assert torch.equal(a, b), k
+        vocab = {f"p{i}": i for i in range(46)}
+        a = APTAI("cpu", vocab, tmp, cfg, None)
+        assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == dict(synth.aptai_param_shapes(cfg))
+        assert a.state_dict()["tv_lowpass.lowpass.weight"].dtype == torch.float64
+        assert set(a.get_config()) == {"device", "vocab", "huggingface_model_id", "pretrain_cfg"}
+        assert not any(p.requires_grad for n, p in a.named_parameters() if "feature_extractor" in n)      # default frozen
+        pr = Wav2Vec2_PR(cfg, None, tmp, vocab)
+        assert {k: tuple(v.shape) for k, v in pr.state_dict().items()} == dict(synth.pr_param_shapes(cfg))
+    with pytest.raises(FileNotFoundError):
+        Wav2Vec2Model.from_pretrained("facebook/wav2vec2-large-robust")        # hub ids cannot be resolved offline
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from aptai_amd import _lib
+    L = _lib.lib()
+    names = _lib.declared_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.aptai_version() >= 100
+    undeclared = [n for n in _lib.ARGTYPES if n not in names]
+    assert not undeclared, undeclared
+
+
+def test_product_never_imports_the_oracle_and_has_no_cpu_fallback():
+    import aptai_amd
+    root = os.path.dirname(aptai_amd.__file__)
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+    from aptai_amd import ops
+    from aptai_amd._lib import AptaiHipError
+    x = torch.zeros(128, 64, dtype=torch.bfloat16)
+    with pytest.raises(AptaiHipError):
+        ops.gemm(x, x, 128, 128, 64)
+    with pytest.raises(AptaiHipError):
+        ops.layernorm_fwd(torch.zeros(4, 256, dtype=torch.bfloat16), torch.ones(256), torch.zeros(256), 1e-5)
