@@ -48,6 +48,19 @@ ARGTYPES = {
     "aptai_aptai_loss_bwd": [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _F, _F, _P, _P, _P, _P, _I64, _P],
     "aptai_aptai_loss_workspace_bytes": [],
     "aptai_gemm_workspace_bytes": [_I64, _I64, _I],
+    "aptai_sgemm_f32": [_P, _I, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _F, _I, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "aptai_embed_pe_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _F, _U64, _P],
+    "aptai_embed_bwd": [_P, _P, _P, _I64, _I64, _F, _U64, _P],
+    "aptai_xattn_softmax_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
+    "aptai_xattn_softmax_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _P],
+    "aptai_layernorm_f32_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P],
+    "aptai_layernorm_f32_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P],
+    "aptai_lstm_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "aptai_lstm_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "aptai_gather_alignment": [_P, _P, _P, _P, _I64, _I64, _I64, _P],
+    "aptai_tanh_dropout_f32": [_P, _P, _P, _P, _I64, _F, _U64, _P],
+    "aptai_dropout_f32": [_P, _P, _I64, _F, _U64, _P],
+    "aptai_colsum_f32": [_P, _I64, _P, _I64, _I64, _P],
     "aptai_ctc_fwd": [_P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _P, _P],
     "aptai_ctc_bwd": [_P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _F, _P, _I64, _I, _P],
     "aptai_ctc_workspace_bytes": [_I64, _I64, _I64],

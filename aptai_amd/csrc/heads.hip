@@ -96,7 +96,7 @@ __global__ void loss_final_kernel(const float* __restrict__ partials, int nblock
     for (int b = 0; b < nblocks; ++b)
         for (int k = 0; k < 4; ++k) s[k] += partials[b * 4 + k];
     const float mse = (float)(s[0] / s[1]);        // 0/0 -> nan like F.mse_loss on an empty selection
-    const float ce = (float)(s[2] / s[3]);
+    const float ce = (w_ce == 0.f && s[3] == 0.0) ? 0.f : (float)(s[2] / s[3]);   // tv-only use (Force_APTAI): no phoneme term
     scalars[0] = w_mse * mse + w_ce * ce;
     scalars[1] = mse;
     scalars[2] = ce;

@@ -46,3 +46,49 @@ class LowPassFilterLayer(nn.Module):
 
     def forward(self, y):
         return _FirFn.apply(y, self.taps())
+
+
+# ------------------------------------------------------------------------------------- Force_APTAI building blocks
+# Parameter holders with the reference's attribute / state-dict names; the arithmetic runs in force_aptai._ForceHeadsFn.
+class CrossAttention(nn.Module):
+    """models/modules.py:129-153 (q, k, layer_norm)."""
+
+    def __init__(self, frame_dim, phn_dim, att_dim):
+        super().__init__()
+        self.q = nn.Linear(frame_dim, att_dim)
+        self.k = nn.Linear(phn_dim, att_dim)
+        self.layer_norm = nn.LayerNorm(att_dim * 2)
+
+
+class RNN(nn.Module):
+    """models/modules.py:190-214 (lstm, linear.0, linear.3)."""
+
+    def __init__(self, hidden_dim, out_dim, drop=0.1):
+        super().__init__()
+        self.lstm = nn.LSTM(hidden_dim, hidden_dim, bidirectional=True, num_layers=1, batch_first=True)
+        self.linear = nn.Sequential(nn.Linear(2 * hidden_dim, hidden_dim), nn.Dropout(drop), nn.Tanh(),
+                                    nn.Linear(hidden_dim, out_dim))
+
+
+class PositionalEncoding(nn.Module):
+    """models/modules.py:217-235: sinusoidal table registered as buffer ``pe`` (max_len, 1, d_model)."""
+
+    def __init__(self, d_model: int, dropout: float = 0.1, max_len: int = 60):
+        super().__init__()
+        import math
+        self.dropout = nn.Dropout(p=dropout)
+        position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, 1, d_model)
+        pe[:, 0, 0::2] = torch.sin(position * div_term)
+        pe[:, 0, 1::2] = torch.cos(position * div_term)
+        self.register_buffer('pe', pe)
+
+
+class ForwardSumLoss(nn.Module):
+    """models/modules.py:65-117: blank log-prob -1 prepended, per-sample log-softmax over N_b+1 classes, CTC with the
+    monotonic targets 1..N_b, mean over the batch — one launch of the CTC kernels for the whole batch."""
+
+    def __init__(self, blank_logprob=-1):
+        super().__init__()
+        self.blank_logprob = blank_logprob

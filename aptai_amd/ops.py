@@ -342,3 +342,124 @@ def ctc_bwd(logits, ldl, rows_per_b, targets_i32, input_lens_i32, target_lens_i3
               int(zero_infinity), alpha.data_ptr(), nll.data_ptr(), _ptr(grad_out), extra_scale, d.data_ptr(), ldd,
               int(out_dtype == torch.bfloat16), _stream())
     return d
+
+
+# ----------------------------------------------------------------------------- Force_APTAI heads (fp32)
+def sgemm(a, sam, sak, b, sbk, sbn, M, N, K, *, out=None, ldc=None, bias=None, alpha=1.0, accumulate=False, batch=1, bsa=0, bsb=0,
+          bsc=0):
+    """C[m][n] (+)= alpha * sum_k A(m,k) B(k,n) + bias[n] with explicit element strides (see aptai_sgemm_f32)."""
+    _dev(a, b, out, bias)
+    if out is None:
+        out = torch.empty((batch * M, N) if batch > 1 else (M, N), device=a.device, dtype=torch.float32)
+        if batch > 1 and bsc == 0:
+            bsc = M * N
+    _lib.call("aptai_sgemm_f32", a.data_ptr(), int(a.dtype == torch.bfloat16), sam, sak, b.data_ptr(), sbk, sbn, out.data_ptr(),
+              ldc if ldc else N, _ptr(bias), alpha, int(accumulate), M, N, K, batch, bsa, bsb, bsc, _stream())
+    return out
+
+
+def linear_f32(x, w, bias=None, *, rows=None, out=None, ldc=None, ldx=None):
+    """y = x W^T + b, x [rows][in] (fp32 or bf16, row stride ldx), W [out][in] fp32."""
+    N, K = w.shape
+    M = rows if rows is not None else x.shape[0]
+    return sgemm(x, ldx if ldx else x.stride(0), 1, w, 1, K, M, N, K, out=out, ldc=ldc, bias=bias)
+
+
+def embed_pe_fwd(ids_i32, emb, pe, N, p, seed):
+    rows, D = ids_i32.numel(), emb.shape[1]
+    out = torch.empty((rows, D), device=emb.device, dtype=torch.float32)
+    _lib.call("aptai_embed_pe_fwd", ids_i32.data_ptr(), emb.data_ptr(), pe.data_ptr(), out.data_ptr(), rows, N, D, p, seed, _stream())
+    return out
+
+
+def embed_bwd(ids_i32, dout, vocab, p, seed):
+    rows, D = dout.shape
+    demb = torch.zeros((vocab, D), device=dout.device, dtype=torch.float32)
+    _lib.call("aptai_embed_bwd", ids_i32.data_ptr(), dout.data_ptr(), demb.data_ptr(), rows, D, p, seed, _stream())
+    return demb
+
+
+def xattn_softmax_fwd(raw, ids_i32, B, T, N):
+    dev = raw.device
+    energy, att, att_log = (torch.empty((B * T, N), device=dev, dtype=torch.float32) for _ in range(3))
+    align = torch.empty((B, T), device=dev, dtype=torch.int64)
+    _lib.call("aptai_xattn_softmax_fwd", raw.data_ptr(), ids_i32.data_ptr(), energy.data_ptr(), att.data_ptr(), att_log.data_ptr(),
+              align.data_ptr(), B, T, N, _stream())
+    return energy, att, att_log, align
+
+
+def xattn_softmax_bwd(att, att_log, d_att, d_attlog):
+    rows, N = att.shape
+    d_raw = torch.empty_like(att)
+    _lib.call("aptai_xattn_softmax_bwd", att.data_ptr(), att_log.data_ptr(), _ptr(d_att), _ptr(d_attlog), d_raw.data_ptr(), rows, N,
+              _stream())
+    return d_raw
+
+
+def layernorm_f32_fwd(x, gamma, beta, eps=1e-5):
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    _lib.call("aptai_layernorm_f32_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), rows, cols, eps, _stream())
+    return y, mean, rstd
+
+
+def layernorm_f32_bwd(dy, x, mean, rstd, gamma):
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.zeros(cols, device=x.device, dtype=torch.float32)
+    db = torch.zeros(cols, device=x.device, dtype=torch.float32)
+    _lib.call("aptai_layernorm_f32_bwd", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+              dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, cols, _stream())
+    return dx, dg, db
+
+
+def lstm_fwd(xproj, whhT, lens_i32, B, Tp, T, save=True):
+    dev = xproj.device
+    hout = torch.empty((B * Tp, 512), device=dev, dtype=torch.float32)
+    gates = torch.zeros((B * Tp, 2048), device=dev, dtype=torch.float32) if save else None
+    cst = torch.zeros((B * Tp, 512), device=dev, dtype=torch.float32) if save else None
+    _lib.call("aptai_lstm_fwd", xproj.data_ptr(), whhT.data_ptr(), lens_i32.data_ptr(), hout.data_ptr(), _ptr(gates), _ptr(cst), B, Tp,
+              T, 256, _stream())
+    return hout, gates, cst
+
+
+def lstm_bwd(dhout, whh, lens_i32, gates, cst, B, Tp, T):
+    dgates = torch.empty_like(gates)
+    _lib.call("aptai_lstm_bwd", dhout.data_ptr(), whh.data_ptr(), lens_i32.data_ptr(), gates.data_ptr(), cst.data_ptr(),
+              dgates.data_ptr(), B, Tp, T, 256, _stream())
+    return dgates
+
+
+def gather_alignment(ids_i32, align, lens_i32, B, T, N):
+    out = torch.empty((B, T), device=align.device, dtype=torch.int64)
+    _lib.call("aptai_gather_alignment", ids_i32.data_ptr(), align.data_ptr(), lens_i32.data_ptr(), out.data_ptr(), B, T, N, _stream())
+    return out
+
+
+def tanh_dropout_fwd(x, p, seed):
+    y = torch.empty_like(x)
+    _lib.call("aptai_tanh_dropout_f32", x.data_ptr(), None, None, y.data_ptr(), x.numel(), p, seed, _stream())
+    return y
+
+
+def tanh_dropout_bwd(y, dy, p, seed):
+    dx = torch.empty_like(y)
+    _lib.call("aptai_tanh_dropout_f32", None, y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(), p, seed, _stream())
+    return dx
+
+
+def dropout_f32(x, p, seed):
+    if p <= 0:
+        return x
+    y = torch.empty_like(x)
+    _lib.call("aptai_dropout_f32", x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _stream())
+    return y
+
+
+def colsum_f32(x, rows, N, ld=None):
+    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    _lib.call("aptai_colsum_f32", x.data_ptr(), ld if ld else x.stride(0), out.data_ptr(), rows, N, _stream())
+    return out

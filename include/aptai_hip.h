@@ -184,6 +184,45 @@ int aptai_ctc_bwd(const float* logits, int64_t ldl, int64_t rows_per_b, const in
                   const float* grad_out, float extra_scale, void* dlogits, int64_t ldd, int out_bf16, void* stream);
 int64_t aptai_ctc_workspace_bytes(int64_t B, int64_t T, int64_t ldt);
 
+/* ------------------------------------------------------------------------------------------------ Force_APTAI heads (fp32)
+ * Small layers behind the frozen encoder of models/force_aptai.py:108-161.  fp32 because they feed an argmax whose
+ * indices must match the reference. */
+/* C[m][n] (+)= alpha*sum_k A(m,k)*B(k,n) + bias[n];  A(m,k)=A[m*sam+k*sak] (fp32, or bf16 when a_bf16),
+ * B(k,n)=B[k*sbk+n*sbn]; `batch` problems at element strides bsa/bsb/bsc.  Replaces nn.Linear (force_aptai.py:122,
+ * modules.py:140-141,195-201) and torch.bmm (modules.py:144,149). */
+int aptai_sgemm_f32(const void* A, int a_bf16, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+                    int64_t ldc, const float* bias, float alpha, int accumulate, int64_t M, int64_t N, int64_t K, int64_t batch,
+                    int64_t bsa, int64_t bsb, int64_t bsc, void* stream);
+/* nn.Embedding(padding_idx=0) + PositionalEncoding (force_aptai.py:118-119, modules.py:217-235): out[r] = emb[ids[r]] + pe[r % N] */
+int aptai_embed_pe_fwd(const int32_t* ids, const float* emb, const float* pe, float* out, int64_t rows, int64_t N, int64_t D,
+                       float dropout_p, uint64_t seed, void* stream);
+int aptai_embed_bwd(const int32_t* ids, const float* dout, float* demb_zeroed, int64_t rows, int64_t D, float dropout_p,
+                    uint64_t seed, void* stream);
+/* CrossAttention softmax + the log-softmax alignment of force_aptai.py:128-130 and its argmax read-out (:148):
+ * energy = raw + mask, att = softmax(energy), att_log = log_softmax(energy + mask), mask = -1000 where phn_ids == 0;
+ * align int64 [B][T] = argmax_n att_log (first maximum), bit-exact integer output. */
+int aptai_xattn_softmax_fwd(const float* raw, const int32_t* phn_ids, float* energy, float* att, float* att_log, int64_t* align,
+                            int64_t B, int64_t T, int64_t N, void* stream);
+int aptai_xattn_softmax_bwd(const float* att, const float* att_log, const float* d_att, const float* d_attlog, float* d_raw,
+                            int64_t rows, int64_t N, void* stream);
+int aptai_layernorm_f32_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows,
+                            int64_t cols, float eps, void* stream);
+int aptai_layernorm_f32_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
+                            float* dgamma_zeroed, float* dbeta_zeroed, int64_t rows, int64_t cols, void* stream);
+/* nn.LSTM(256,256,bidirectional) over packed sequences (modules.py:195,204-206): xproj [B*Tp][2][1024] = x W_ih^T + b_ih + b_hh,
+ * whhT [2][256][1024] (transposed weight_hh), lens int32 [B]; hout [B*Tp][512] (zeros beyond lens); gates/cstate saved for bwd. */
+int aptai_lstm_fwd(const float* xproj, const float* whhT, const int32_t* lens, float* hout, float* gates, float* cstate, int64_t B,
+                   int64_t Tp, int64_t T, int64_t hidden, void* stream);
+int aptai_lstm_bwd(const float* dhout, const float* whh, const int32_t* lens, const float* gates, const float* cstate, float* dgates,
+                   int64_t B, int64_t Tp, int64_t T, int64_t hidden, void* stream);
+/* pred_frame_phns (force_aptai.py:152-161): out[b][t] = phn_table[b][align[b][t]] for t < lens[b], else -1 (int64) */
+int aptai_gather_alignment(const int32_t* phn_table, const int64_t* align, const int32_t* lens, int64_t* out, int64_t B, int64_t T,
+                           int64_t N, void* stream);
+int aptai_tanh_dropout_f32(const float* x, const float* y_or_null, const float* dy_or_null, float* out, int64_t n, float dropout_p,
+                           uint64_t seed, void* stream);
+int aptai_dropout_f32(const float* x, float* y, int64_t n, float dropout_p, uint64_t seed, void* stream);
+int aptai_colsum_f32(const float* x, int64_t ld, float* out, int64_t rows, int64_t N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
