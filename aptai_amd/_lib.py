@@ -25,7 +25,7 @@ _P, _I64, _I, _F, _U64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c
 # argument types of every entry point except aptai_gemm_bf16 (descriptor struct, see ops.GemmDesc)
 ARGTYPES = {
     "aptai_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _I, _P],
-    "aptai_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _P, _P, _P, _I64, _I64, _P],
+    "aptai_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _P, _P, _P, _I64, _I64, _P, _P],
     "aptai_layernorm_bwd_workspace_bytes": [_I64, _I64],
     "aptai_attention_fwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _U64, _P],
     "aptai_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _U64, _I, _P],
@@ -39,7 +39,10 @@ ARGTYPES = {
     "aptai_colsum_bf16": [_P, _I64, _P, _P, _I64, _I64, _I, _P],
     "aptai_colsum_workspace_bytes": [_I64, _I64],
     "aptai_dropout_bf16": [_P, _P, _I64, _F, _U64, _P],
-    "aptai_conv0_fwd": [_P, _I64, _I64, _P, _P, _P, _P, _I, _F, _P, _I64, _I64, _I64, _I64, _I64, _P, _P],
+    "aptai_dgelu_bf16": [_P, _P, _P, _I64, _P],
+    "aptai_conv0_fwd": [_P, _I64, _I64, _P, _P, _P, _P, _I, _F, _P, _I64, _I64, _I64, _I64, _I64, _P, _P, _P],
+    "aptai_conv0_bwd": [_P, _I64, _I64, _P, _P, _P, _P, _I, _F, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P],
+    "aptai_conv0_bwd_workspace_bytes": [_I64, _I64],
     "aptai_conv0_workspace_bytes": [_I64, _I64],
     "aptai_head_act_fwd": [_P, _P, _P, _I64, _F, _F, _U64, _P],
     "aptai_head_act_bwd": [_P, _P, _P, _P, _I64, _F, _F, _U64, _P],

@@ -161,6 +161,191 @@ __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args a) {
     }
 }
 
+
+// ====================================================================================== backward of layer 0
+// The conv output is never stored: every pass recomputes it from the waveform (10 MACs/output) and fuses GELU', the
+// norm backward and the weight-gradient accumulation.  Weight/affine gradients are reduced deterministically:
+// per-block partials -> one small reduction.
+constexpr int BWD_FRAMES_PER_BLOCK = 256;
+
+struct Conv0BwdArgs {
+    Conv0Args f;                // forward description (audio, weights, stats, T_real, T_alloc, eps, nchunks)
+    const bf16_t* dy;           // [B][T_alloc][512]
+    float* gpart;               // group mode: [B][nchunks][2][512] sums of dgn and dgn*xhat
+    const float* gmean;         // group mode: [B][2][512] = (mean_t dgn, mean_t dgn*xhat)
+    float* wpart;               // [B][nchunks][512][13]: 10 taps, dbias, dgamma, dbeta partials
+};
+
+__device__ __forceinline__ void load8bf(const bf16_t* p, float (&o)[8]) {
+    const u32x4 v = *(const u32x4*)p;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o[2 * r] = lo_bf(v[r]); o[2 * r + 1] = hi_bf(v[r]); }
+}
+
+// group mode, pass A: partial sums over frames of dgn and dgn*xhat per (b, channel)
+__global__ __launch_bounds__(256) void conv0_bwd_group_stats_kernel(Conv0BwdArgs a) {
+    __shared__ float red[4][2][C0];
+    const Conv0Args& f = a.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    float w[8][KW], bias[8], mu[8], rs[8], gm[8], bt[8];
+    load_weights(f, lane, w, bias);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane * 8 + j;
+        mu[j] = f.stats[((long)b * 2 + 0) * C0 + c]; rs[j] = f.stats[((long)b * 2 + 1) * C0 + c];
+        gm[j] = f.gamma[c]; bt[j] = f.beta[c];
+    }
+    const float* xb = f.audio + (long)b * f.S;
+    const bf16_t* dyb = a.dy + (long)b * f.T_alloc * C0;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    const int t0 = chunk * BWD_FRAMES_PER_BLOCK;
+    int t1 = t0 + BWD_FRAMES_PER_BLOCK;
+    t1 = t1 < f.T_real ? t1 : f.T_real;
+    for (int t = t0 + wave; t < t1; t += 4) {
+        float v[8], d[8];
+        conv_frame(xb + (long)t * STRIDE, w, bias, v);
+        load8bf(dyb + (long)t * C0 + lane * 8, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = (v[j] - mu[j]) * rs[j];
+            const float dgn = d[j] * gelu_fast_grad(fmaf(xh, gm[j], bt[j]));
+            s1[j] += dgn;
+            s2[j] = fmaf(dgn, xh, s2[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[wave][0][lane * 8 + j] = s1[j]; red[wave][1][lane * 8 + j] = s2[j]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C0; i += 256) {
+        const int which = i / C0, c = i % C0;
+        a.gpart[(((long)b * f.nchunks + chunk) * 2 + which) * C0 + c] =
+            red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+}
+
+// sums over chunks (double) -> per-(b,c) means; also dgamma/dbeta = sums over b of the totals
+__global__ void conv0_bwd_group_final_kernel(const float* __restrict__ gpart, float* __restrict__ gmean, float* __restrict__ dgamma,
+                                             float* __restrict__ dbeta, int B, int nchunks, int T_real) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C0) return;
+    double tg = 0.0, tb = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nchunks; ++k) {
+            s1 += (double)gpart[(((long)b * nchunks + k) * 2 + 0) * C0 + c];
+            s2 += (double)gpart[(((long)b * nchunks + k) * 2 + 1) * C0 + c];
+        }
+        gmean[((long)b * 2 + 0) * C0 + c] = (float)(s1 / T_real);
+        gmean[((long)b * 2 + 1) * C0 + c] = (float)(s2 / T_real);
+        tb += s1;
+        tg += s2;
+    }
+    if (dgamma) dgamma[c] = (float)tg;
+    if (dbeta) dbeta[c] = (float)tb;
+}
+
+// pass B (both modes): du per frame -> per-block partials of dW (10 taps), dbias, and (layer mode) dgamma/dbeta
+template <int MODE>
+__global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(Conv0BwdArgs a) {
+    __shared__ float red[4][C0];
+    const Conv0Args& f = a.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    float w[8][KW], bias[8], gm[8], bt[8], mu[8], rs[8], m1[8], m2[8];
+    load_weights(f, lane, w, bias);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane * 8 + j;
+        gm[j] = f.gamma[c]; bt[j] = f.beta[c];
+        if (MODE == 0) {
+            mu[j] = f.stats[((long)b * 2 + 0) * C0 + c]; rs[j] = f.stats[((long)b * 2 + 1) * C0 + c];
+            m1[j] = a.gmean[((long)b * 2 + 0) * C0 + c]; m2[j] = a.gmean[((long)b * 2 + 1) * C0 + c];
+        }
+    }
+    const float* xb = f.audio + (long)b * f.S;
+    const bf16_t* dyb = a.dy + (long)b * f.T_alloc * C0;
+    float acc[8][13];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < 13; ++k) acc[j][k] = 0.f;
+    const int t0 = chunk * BWD_FRAMES_PER_BLOCK;
+    int t1 = t0 + BWD_FRAMES_PER_BLOCK;
+    t1 = t1 < f.T_real ? t1 : f.T_real;
+    for (int t = t0 + wave; t < t1; t += 4) {
+        float v[8], d[8], du[8], smp[KW];
+        const float* xs = xb + (long)t * STRIDE;
+        conv_frame(xs, w, bias, v);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) smp[k] = xs[k];
+        load8bf(dyb + (long)t * C0 + lane * 8, d);
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (v[j] - mu[j]) * rs[j];
+                const float dgn = d[j] * gelu_fast_grad(fmaf(xh, gm[j], bt[j]));
+                du[j] = gm[j] * rs[j] * (dgn - m1[j] - xh * m2[j]);
+            }
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+            const float mean = wave_sum(s) * (1.0f / C0);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float e = v[j] - mean; q += e * e; }
+            const float rstd = rsqrtf(wave_sum(q) * (1.0f / C0) + f.eps);
+            float xh[8], gd[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xh[j] = (v[j] - mean) * rstd;
+                const float dln = d[j] * gelu_fast_grad(fmaf(xh[j], gm[j], bt[j]));
+                acc[j][11] = fmaf(dln, xh[j], acc[j][11]);      // dgamma
+                acc[j][12] += dln;                               // dbeta
+                gd[j] = dln * gm[j];
+                s1 += gd[j];
+                s2 = fmaf(gd[j], xh[j], s2);
+            }
+            s1 = wave_sum(s1) * (1.0f / C0);
+            s2 = wave_sum(s2) * (1.0f / C0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) du[j] = rstd * (gd[j] - s1 - xh[j] * s2);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int k = 0; k < KW; ++k) acc[j][k] = fmaf(du[j], smp[k], acc[j][k]);
+            acc[j][10] += du[j];                                 // dbias
+        }
+    }
+    // combine the 4 waves, one of the 13 quantities at a time
+    float* out = a.wpart + ((long)b * f.nchunks + chunk) * C0 * 13;
+    for (int k = 0; k < 13; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave][lane * 8 + j] = acc[j][k];
+        __syncthreads();
+        for (int c = threadIdx.x; c < C0; c += 256) out[(long)c * 13 + k] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    }
+}
+
+// dweight [512][10], dbias [512], (layer mode) dgamma/dbeta [512] = sum over (b, chunk) partials
+__global__ void conv0_bwd_reduce_kernel(const float* __restrict__ wpart, int nparts, float* __restrict__ dweight, float* __restrict__ dbias,
+                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C0 * 13) return;
+    const int c = i / 13, k = i % 13;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += (double)wpart[(long)p * C0 * 13 + i];
+    if (k < KW) dweight[c * KW + k] = (float)s;
+    else if (k == 10) { if (dbias) dbias[c] = (float)s; }
+    else if (k == 11) { if (dgamma) dgamma[c] = (float)s; }
+    else { if (dbeta) dbeta[c] = (float)s; }
+}
+
 }  // namespace
 
 extern "C" int64_t aptai_conv0_workspace_bytes(int64_t B, int64_t T_real) {
@@ -170,7 +355,8 @@ extern "C" int64_t aptai_conv0_workspace_bytes(int64_t B, int64_t T_real) {
 
 extern "C" int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias,
                                const float* gamma, const float* beta, int mode, float eps, void* out, int64_t T_real,
-                               int64_t T_alloc, int64_t C, int64_t Kw, int64_t stride, void* workspace, void* stream_) {
+                               int64_t T_alloc, int64_t C, int64_t Kw, int64_t stride, void* workspace, float* stats_out,
+                               void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APTAI_REQUIRE(audio && weight && gamma && beta && out, "aptai_conv0_fwd: null pointer");
     APTAI_REQUIRE(C == C0 && Kw == KW && stride == STRIDE, "aptai_conv0_fwd: built for C=512, k=10, s=5 (got %ld,%ld,%ld)",
@@ -192,7 +378,7 @@ extern "C" int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const f
     APTAI_REQUIRE(workspace != nullptr, "aptai_conv0_fwd: group mode needs a workspace");
     a.nchunks = (int)ceil_div(T_real, FRAMES_PER_BLOCK_STATS);
     a.partials = (float*)workspace;
-    float* stats = (float*)workspace + (long)B * a.nchunks * 2 * C0;
+    float* stats = stats_out ? stats_out : (float*)workspace + (long)B * a.nchunks * 2 * C0;
     a.stats = stats;
     APTAI_LAUNCH(conv0_stats_kernel, dim3((unsigned)a.nchunks, (unsigned)B), dim3(256), 0, stream, a);
     APTAI_CHECK_LAUNCH("conv0_stats_kernel");
@@ -201,5 +387,49 @@ extern "C" int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const f
     APTAI_CHECK_LAUNCH("conv0_stats_final_kernel");
     APTAI_LAUNCH(conv0_group_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, a);
     APTAI_CHECK_LAUNCH("conv0_group_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int64_t aptai_conv0_bwd_workspace_bytes(int64_t B, int64_t T_real) {
+    const long nch = ceil_div(T_real, BWD_FRAMES_PER_BLOCK);
+    return (B * nch * 2 * C0 + B * 2 * C0 + B * nch * C0 * 13) * 4;
+}
+
+/* stats: the [B][2][512] (mean, rstd) block the forward left at the END of its workspace (group mode); null in layer mode */
+extern "C" int aptai_conv0_bwd(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias, const float* gamma,
+                               const float* beta, int mode, float eps, const void* dy, int64_t T_real, int64_t T_alloc,
+                               const float* fwd_stats, float* dweight, float* dbias, float* dgamma, float* dbeta, void* workspace,
+                               void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APTAI_REQUIRE(audio && weight && gamma && beta && dy && dweight && workspace, "aptai_conv0_bwd: null pointer");
+    APTAI_REQUIRE(mode == 0 || mode == 1, "aptai_conv0_bwd: mode");
+    APTAI_REQUIRE(mode == 1 || fwd_stats, "aptai_conv0_bwd: group mode needs the forward statistics");
+    APTAI_REQUIRE((T_real - 1) * STRIDE + KW <= S && T_alloc >= T_real, "aptai_conv0_bwd: bad frame counts");
+    Conv0BwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.f.audio = audio; a.f.S = S; a.f.w = weight; a.f.bias = bias; a.f.gamma = gamma; a.f.beta = beta; a.f.B = (int)B;
+    a.f.T_real = (int)T_real; a.f.T_alloc = (int)T_alloc; a.f.eps = eps; a.f.stats = fwd_stats;
+    a.f.nchunks = (int)ceil_div(T_real, BWD_FRAMES_PER_BLOCK);
+    a.dy = (const bf16_t*)dy;
+    float* ws = (float*)workspace;
+    a.gpart = ws;
+    float* gmean = ws + (long)B * a.f.nchunks * 2 * C0;
+    a.gmean = gmean;
+    a.wpart = gmean + (long)B * 2 * C0;
+    dim3 grid((unsigned)a.f.nchunks, (unsigned)B);
+    if (mode == 0) {
+        APTAI_LAUNCH(conv0_bwd_group_stats_kernel, grid, dim3(256), 0, stream, a);
+        APTAI_CHECK_LAUNCH("conv0_bwd_group_stats_kernel");
+        APTAI_LAUNCH(conv0_bwd_group_final_kernel, dim3(2), dim3(256), 0, stream, (const float*)a.gpart, gmean, dgamma, dbeta, (int)B,
+                     a.f.nchunks, (int)T_real);
+        APTAI_CHECK_LAUNCH("conv0_bwd_group_final_kernel");
+        APTAI_LAUNCH(conv0_bwd_weight_kernel<0>, grid, dim3(256), 0, stream, a);
+    } else {
+        APTAI_LAUNCH(conv0_bwd_weight_kernel<1>, grid, dim3(256), 0, stream, a);
+    }
+    APTAI_CHECK_LAUNCH("conv0_bwd_weight_kernel");
+    APTAI_LAUNCH(conv0_bwd_reduce_kernel, dim3((unsigned)ceil_div(C0 * 13, 256)), dim3(256), 0, stream, (const float*)a.wpart,
+                 (int)(B * a.f.nchunks), dweight, bias ? dbias : nullptr, mode == 1 ? dgamma : nullptr, mode == 1 ? dbeta : nullptr);
+    APTAI_CHECK_LAUNCH("conv0_bwd_reduce_kernel");
     return APTAI_OK;
 }

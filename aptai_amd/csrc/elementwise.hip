@@ -229,6 +229,19 @@ __global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict_
         y[i] = drop_keep((uint64_t)i, s0, s1, thr) ? f2bf(bf2f(x[i]) * sc) : (bf16_t)0;
 }
 
+// out = dy * gelu'(u)   (backward of a standalone GELU; 8 elements per thread)
+__global__ void dgelu_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ out, long n8) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const u32x4 d = ((const u32x4*)dy)[i], x = ((const u32x4*)u)[i];
+        u32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            o[r] = pack2bf(lo_bf(d[r]) * gelu_fast_grad(lo_bf(x[r])), hi_bf(d[r]) * gelu_fast_grad(hi_bf(x[r])));
+        ((u32x4*)out)[i] = o;
+    }
+}
+
 inline unsigned grid_for(long n, int block = 256, int max_blocks = 4096) {
     long b = ceil_div(n, block);
     return (unsigned)(b < 1 ? 1 : (b > max_blocks ? max_blocks : b));
@@ -355,5 +368,13 @@ extern "C" int aptai_dropout_bf16(const void* x, void* y, int64_t n, float p, ui
     APTAI_LAUNCH(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
                        (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t, drop_scale(t));
     APTAI_CHECK_LAUNCH("dropout_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_dgelu_bf16(const void* dy, const void* u, void* out, int64_t n, void* stream) {
+    APTAI_REQUIRE(dy && u && out && n > 0 && n % 8 == 0, "aptai_dgelu_bf16: bad arguments (n %% 8 == 0)");
+    APTAI_LAUNCH(dgelu_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)u,
+                 (bf16_t*)out, (long)(n / 8));
+    APTAI_CHECK_LAUNCH("dgelu_kernel");
     return APTAI_OK;
 }

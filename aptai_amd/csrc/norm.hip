@@ -64,16 +64,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ gamma, const bf16_t* __restrict__ dres,
                                                      bf16_t* __restrict__ dx, bf16_t* __restrict__ dx_drop,
                                                      uint32_t seed0, uint32_t seed1, uint32_t thr16, float dscale,
-                                                     float* __restrict__ partials, long rows) {
+                                                     float* __restrict__ partials, long rows, const float* __restrict__ beta_gelu) {
     constexpr int COLS = NCH * 256;
     __shared__ float red[4][2][COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float gm[NCH][4], dg[NCH][4], db[NCH][4];
+    float gm[NCH][4], dg[NCH][4], db[NCH][4], bt[NCH][4];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const f32x4 g4 = *(const f32x4*)(gamma + (j * 64 + lane) * 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { gm[j][r] = g4[r]; dg[j][r] = 0.f; db[j][r] = 0.f; }
+        for (int r = 0; r < 4; ++r) { gm[j][r] = g4[r]; dg[j][r] = 0.f; db[j][r] = 0.f; bt[j][r] = 0.f; }
+        if (beta_gelu) {
+            const f32x4 b4 = *(const f32x4*)(beta_gelu + (j * 64 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bt[j][r] = b4[r];
+        }
     }
     for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -85,10 +90,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             const u32x2 px = *(const u32x2*)(x + off);
             const u32x2 pd = *(const u32x2*)(dy + off);
             const float xv[4] = {lo_bf(px[0]), hi_bf(px[0]), lo_bf(px[1]), hi_bf(px[1])};
-            const float dv[4] = {lo_bf(pd[0]), hi_bf(pd[0]), lo_bf(pd[1]), hi_bf(pd[1])};
+            float dv[4] = {lo_bf(pd[0]), hi_bf(pd[0]), lo_bf(pd[1]), hi_bf(pd[1])};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 xh[j][r] = (xv[r] - mu) * rs;
+                if (beta_gelu) dv[r] *= gelu_fast_grad(fmaf(xh[j][r], gm[j][r], bt[j][r]));   // y = gelu(LN(x)): fold gelu' into dy
                 gd[j][r] = dv[r] * gm[j][r];
                 s1 += gd[j][r];
                 s2 += gd[j][r] * xh[j][r];
@@ -187,7 +193,7 @@ extern "C" int64_t aptai_layernorm_bwd_workspace_bytes(int64_t rows, int64_t col
 extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
                                    const float* gamma, const void* dres, void* dx, void* dx_drop, float dropout_p,
                                    uint64_t seed, float* dgamma, float* dbeta, void* workspace, int64_t rows,
-                                   int64_t cols, void* stream_) {
+                                   int64_t cols, const float* beta_if_gelu_after, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     APTAI_REQUIRE(dy && x && mean && rstd && gamma && dx && workspace, "aptai_layernorm_bwd: null pointer");
     APTAI_REQUIRE(cols % 256 == 0 && cols >= 256 && cols <= 1024, "aptai_layernorm_bwd: cols=%ld", (long)cols);
@@ -197,7 +203,7 @@ extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* m
     const uint32_t thr = drop_thr16(dropout_p);
     void* dxd = thr ? dx_drop : nullptr;
     if (dx_drop && !thr) APTAI_FAIL(APTAI_ERR_INVALID, "aptai_layernorm_bwd: dx_drop given with dropout_p == 0");
-#define LN_BWD(NCH) APTAI_LAUNCH(ln_bwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows)
+#define LN_BWD(NCH) APTAI_LAUNCH(ln_bwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows, beta_if_gelu_after)
     switch (cols / 256) {
         case 1: LN_BWD(1); break;
         case 2: LN_BWD(2); break;

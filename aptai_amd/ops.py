@@ -70,7 +70,8 @@ def _dev(*ts) -> None:
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, ldb=None, out=None, ldc=None,
          a_kmajor=False, b_kmajor=False, out_f32=False, bias=None, gelu=False, residual=None, out_pre=None,
          dgelu_aux=None, alpha: Optional[float] = None, dropout_p: float = 0.0, seed: int = 0, split_k: int = 1,
-         accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None, tile: int = 0) -> torch.Tensor:
+         accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None, tile: int = 0,
+         ldaux=None) -> torch.Tensor:
     """C[M,N] = rowop(A)[M,K] . colop(B)[N,K]^T.  See aptai_gemm_bf16 in include/aptai_hip.h."""
     _dev(a, b, out, bias, residual, out_pre, dgelu_aux)
     if out is None:
@@ -104,6 +105,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
     d.flags = flags
     d.split_k, d.accumulate = split_k, int(accumulate)
     d.tile = tile
+    if ldaux is not None:
+        d.ldaux = ldaux
     if ldr is not None:
         d.ldr = ldr
     if batch is not None:
@@ -149,7 +152,7 @@ def layernorm_fwd(x, gamma, beta, eps, *, gelu_after=False, save_stats=True, out
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, *, dres=None, dropout_p=0.0, seed=0, need_param_grads=True):
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, dres=None, dropout_p=0.0, seed=0, need_param_grads=True, beta_gelu=None):
     """Returns (dx, dx_drop | None, dgamma | None, dbeta | None)."""
     _dev(dy, x, mean, rstd, gamma, dres)
     rows, cols = x.shape
@@ -162,7 +165,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dres=None, dropout_p=0.0, seed=0,
     ws = _ws(_lib.lib().aptai_layernorm_bwd_workspace_bytes(rows, cols), x.device)
     _lib.call("aptai_layernorm_bwd", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
               _ptr(dres), dx.data_ptr(), _ptr(dx_drop), dropout_p, seed, _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), rows,
-              cols, _stream())
+              cols, _ptr(beta_gelu), _stream())
     return dx, dx_drop, dgamma, dbeta
 
 
@@ -259,15 +262,41 @@ def dropout(x, p, seed):
     return y
 
 
+def dgelu(dy, u):
+    _dev(dy, u)
+    out = torch.empty_like(dy)
+    _lib.call("aptai_dgelu_bf16", dy.data_ptr(), u.data_ptr(), out.data_ptr(), dy.numel(), _stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- conv layer 0
-def conv0_fwd(audio, weight, bias, gamma, beta, mode, out, T_real, T_alloc, eps=1e-5):
+def conv0_fwd(audio, weight, bias, gamma, beta, mode, out, T_real, T_alloc, eps=1e-5, want_stats=False):
+    """Returns the (mean, rstd) block [B][2][512] in group mode when ``want_stats`` (needed by conv0_bwd)."""
     _dev(audio, weight, bias, gamma, beta, out)
     B, S = audio.shape
     C, _, Kw = weight.shape
     ws = _ws(_lib.lib().aptai_conv0_workspace_bytes(B, T_real), audio.device) if mode == 0 else None
+    stats = torch.empty((B, 2, C), device=audio.device, dtype=torch.float32) if (want_stats and mode == 0) else None
     _lib.call("aptai_conv0_fwd", audio.data_ptr(), B, S, weight.data_ptr(), _ptr(bias), gamma.data_ptr(), beta.data_ptr(), mode,
-              eps, out.data_ptr(), T_real, T_alloc, C, Kw, 5, _ptr(ws), _stream())
-    return out
+              eps, out.data_ptr(), T_real, T_alloc, C, Kw, 5, _ptr(ws), _ptr(stats), _stream())
+    return stats
+
+
+def conv0_bwd(audio, weight, bias, gamma, beta, mode, dy, T_real, T_alloc, stats, eps=1e-5):
+    """Returns (dweight [512][1][10], dbias | None, dgamma, dbeta)."""
+    _dev(audio, weight, bias, gamma, beta, dy, stats)
+    B, S = audio.shape
+    C = weight.shape[0]
+    dev = audio.device
+    dw = torch.empty_like(weight)
+    db = torch.empty(C, device=dev, dtype=torch.float32) if bias is not None else None
+    dg = torch.empty(C, device=dev, dtype=torch.float32)
+    dbt = torch.empty(C, device=dev, dtype=torch.float32)
+    ws = _ws(_lib.lib().aptai_conv0_bwd_workspace_bytes(B, T_real), dev)
+    _lib.call("aptai_conv0_bwd", audio.data_ptr(), B, S, weight.data_ptr(), _ptr(bias), gamma.data_ptr(), beta.data_ptr(), mode, eps,
+              dy.data_ptr(), T_real, T_alloc, _ptr(stats), dw.data_ptr(), _ptr(db), dg.data_ptr(), dbt.data_ptr(), ws.data_ptr(),
+              _stream())
+    return dw, db, dg, dbt
 
 
 # ----------------------------------------------------------------------------- APTAI heads

@@ -83,6 +83,23 @@ def _run(impl, x, *params):
     return _OpFn.apply(impl, need, x, *params)
 
 
+class _ConvStackFn(torch.autograd.Function):
+    """Trainable feature encoder (Wav2Vec2_PR fine-tuning, train/train_phoneme_recognizer.py): forward saves the layer
+    outputs / pre-activations, backward = Wav2Vec2Model._conv_backward."""
+
+    @staticmethod
+    def forward(ctx, audio, model, g, *params):
+        feats, sv = model._conv_forward(audio, g, save=True)
+        ctx.model, ctx.g, ctx.sv = model, g, sv
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeats):
+        grads = ctx.model._conv_backward(ctx.sv, ctx.g, dfeats.contiguous())
+        ctx.sv = None
+        return (None, None, None) + tuple(grads)
+
+
 def _seed(base: int, *ids: int) -> int:
     s = base & 0xFFFFFFFFFFFF
     for i in ids:
@@ -513,34 +530,119 @@ class Wav2Vec2Model(nn.Module):
         params = [l.conv.weight for l in cl[1:]]
         return self._cached(("convw",), params, lambda: [ops.conv_weight_bf16(p) for p in params])
 
-    def _feature_encoder(self, audio: torch.Tensor, g) -> torch.Tensor:
+    def _conv_params(self):
+        """Flat parameter list of the conv stack in a fixed order: per layer weight, [bias], [norm weight, norm bias]."""
+        cfg = self.config
+        out = []
+        for i, l in enumerate(self.feature_extractor.conv_layers):
+            out.append(l.conv.weight)
+            if cfg.conv_bias:
+                out.append(l.conv.bias)
+            if cfg.feat_extract_norm == "layer" or i == 0:
+                out += [l.layer_norm.weight, l.layer_norm.bias]
+        return out
+
+    def _conv_forward(self, audio, g, save):
+        """7-layer feature encoder (HF:382-419).  Returns (features [M][512] bf16, saved-for-backward | None)."""
         cfg = self.config
         cl = self.feature_extractor.conv_layers
-        trainable = torch.is_grad_enabled() and any(p.requires_grad for p in self.feature_extractor.parameters())
-        if trainable:
-            raise NotImplementedError(
-                "backward through the conv feature encoder is not built yet: call freeze_feature_encoder() "
-                "(APTAI's default, models/aptai.py:24,39) or run under torch.no_grad()")
-        with torch.no_grad():
-            dev = audio.device
-            C = 512
-            layer_mode = cfg.feat_extract_norm == "layer"
-            buf = torch.zeros((g.B * g.alloc[0] + 8, C), device=dev, dtype=torch.bfloat16)
-            l0 = cl[0]
-            ops.conv0_fwd(audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight,
-                          l0.layer_norm.bias, 1 if layer_mode else 0, buf, g.Tl[0], g.alloc[0])
-            ws = self._conv_weights()
-            for i in range(1, len(cl)):
-                k, s = cfg.conv_kernel[i], cfg.conv_stride[i]
-                Mi = g.B * g.alloc[i]
-                out = torch.zeros((Mi + 8, C), device=dev, dtype=torch.bfloat16)
-                bias = cl[i].conv.bias if cfg.conv_bias else None
-                ops.gemm(buf, ws[i - 1], Mi, C, k * C, lda=s * C, out=out, ldc=C, bias=bias, gelu=not layer_mode)
-                if layer_mode:
-                    ops.layernorm_fwd(out[:Mi], cl[i].layer_norm.weight, cl[i].layer_norm.bias, 1e-5, gelu_after=True,
-                                      save_stats=False, out=out[:Mi])
-                buf = out
-            return buf[:g.M]
+        dev = audio.device
+        C = 512
+        layer_mode = cfg.feat_extract_norm == "layer"
+        sv = SimpleNamespace(bufs=[], pre=[None], stats=[None], audio=audio) if save else None
+        buf = torch.zeros((g.B * g.alloc[0] + 8, C), device=dev, dtype=torch.bfloat16)
+        l0 = cl[0]
+        stats0 = ops.conv0_fwd(audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight,
+                               l0.layer_norm.bias, 1 if layer_mode else 0, buf, g.Tl[0], g.alloc[0], want_stats=save)
+        if save:
+            sv.bufs.append(buf)
+            sv.stats0 = stats0
+        ws = self._conv_weights()
+        for i in range(1, len(cl)):
+            k, s = cfg.conv_kernel[i], cfg.conv_stride[i]
+            Mi = g.B * g.alloc[i]
+            out = torch.zeros((Mi + 8, C), device=dev, dtype=torch.bfloat16)
+            bias = cl[i].conv.bias if cfg.conv_bias else None
+            if layer_mode:
+                u = torch.zeros((Mi + 8, C), device=dev, dtype=torch.bfloat16) if save else out
+                ops.gemm(buf, ws[i - 1], Mi, C, k * C, lda=s * C, out=u, ldc=C, bias=bias)
+                _, m, r = ops.layernorm_fwd(u[:Mi], cl[i].layer_norm.weight, cl[i].layer_norm.bias, 1e-5, gelu_after=True,
+                                            save_stats=save, out=out[:Mi])
+                if save:
+                    sv.pre.append(u)
+                    sv.stats.append((m, r))
+            else:
+                u = torch.zeros((Mi + 8, C), device=dev, dtype=torch.bfloat16) if save else None
+                ops.gemm(buf, ws[i - 1], Mi, C, k * C, lda=s * C, out=out, ldc=C, bias=bias, gelu=True, out_pre=u)
+                if save:
+                    sv.pre.append(u)
+                    sv.stats.append(None)
+            buf = out
+            if save:
+                sv.bufs.append(buf)
+        return buf[:g.M], sv
+
+    def _conv_backward(self, sv, g, dfeats):
+        """Gradients of every conv-stack parameter (order of _conv_params).  dgrad of a strided conv = the weight GEMM on the
+        SAME overlapping-row view: columns [0, s*C) of the virtual-row gradient own frames s*t .. s*t+s-1 outright, the
+        remaining (k-s)*C columns are accumulated one virtual row later."""
+        cfg = self.config
+        cl = self.feature_extractor.conv_layers
+        C = 512
+        layer_mode = cfg.feat_extract_norm == "layer"
+        ws = self._conv_weights()
+        dev = dfeats.device
+        grads = {}
+        dy = dfeats                                          # gradient w.r.t. the OUTPUT of layer i (post-activation)
+        du_ready = False                                     # base mode: dgrad epilogues already applied gelu' of the layer below
+        for i in range(len(cl) - 1, 0, -1):
+            k, s = cfg.conv_kernel[i], cfg.conv_stride[i]
+            Mi = g.B * g.alloc[i]
+            x_in = sv.bufs[i - 1]
+            if layer_mode:
+                m, r = sv.stats[i]
+                du, _, dgam, dbet = ops.layernorm_bwd(dy[:Mi], sv.pre[i][:Mi], m, r, cl[i].layer_norm.weight,
+                                                      beta_gelu=cl[i].layer_norm.bias)
+                grads[(i, "ln_w")], grads[(i, "ln_b")] = dgam, dbet
+            else:
+                du = dy[:Mi] if du_ready else ops.dgelu(dy[:Mi].contiguous(), sv.pre[i][:Mi])
+            if cfg.conv_bias:
+                grads[(i, "b")] = ops.colsum(du, Mi, C)
+            sk = max(1, min(16, Mi // 4096))
+            dw = ops.gemm(du, x_in, C, k * C, Mi, a_kmajor=True, b_kmajor=True, out_f32=True, ldb=s * C, split_k=sk)
+            grads[(i, "w")] = dw.view(C, k, C).permute(0, 2, 1).contiguous()          # [N][kw][c] -> nn.Conv1d's [N][c][kw]
+            # ---- dgrad into the output of layer i-1
+            dx = torch.zeros((g.B * g.alloc[i - 1] + 8, C), device=dev, dtype=torch.bfloat16)
+            fuse = (not layer_mode) and (i - 1 >= 1)         # base: fold gelu'(u_{i-1}) into the epilogue
+            aux = sv.pre[i - 1] if fuse else None
+            ops.gemm(du, ws[i - 1], Mi, s * C, C, b_kmajor=True, ldb=k * C, out=dx, ldc=s * C, dgelu_aux=aux,
+                     **({"ldaux": s * C} if fuse else {}))
+            if k > s:
+                n2 = (k - s) * C
+                ops.gemm(du, ws[i - 1][:, s * C:], Mi, n2, C, b_kmajor=True, ldb=k * C, out=dx[s:], ldc=s * C, residual=dx[s:],
+                         ldr=s * C, dgelu_aux=(aux[s:] if fuse else None), **({"ldaux": s * C} if fuse else {}))
+            dy = dx
+            du_ready = fuse
+        l0 = cl[0]
+        dw0, db0, dg0, dbt0 = ops.conv0_bwd(sv.audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight,
+                                            l0.layer_norm.bias, 1 if layer_mode else 0, dy, g.Tl[0], g.alloc[0], sv.stats0)
+        grads[(0, "w")], grads[(0, "b")], grads[(0, "ln_w")], grads[(0, "ln_b")] = dw0, db0, dg0, dbt0
+        out = []
+        for i in range(len(cl)):
+            out.append(grads[(i, "w")])
+            if cfg.conv_bias:
+                out.append(grads[(i, "b")])
+            if layer_mode or i == 0:
+                out += [grads[(i, "ln_w")], grads[(i, "ln_b")]]
+        return out
+
+    def _feature_encoder(self, audio: torch.Tensor, g) -> torch.Tensor:
+        params = self._conv_params()
+        trainable = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if not trainable:
+            with torch.no_grad():
+                return self._conv_forward(audio, g, save=False)[0]
+        return _ConvStackFn.apply(audio, self, g, *params)
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_values, attention_mask=None, mask_time_indices=None, output_attentions=None,

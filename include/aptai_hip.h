@@ -84,7 +84,8 @@ int aptai_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
  * branch that went through nn.Dropout, HF:591,628); dgamma/dbeta fp32 [cols] (overwritten). */
 int aptai_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         const void* dres, void* dx, void* dx_drop, float dropout_p, uint64_t seed, float* dgamma,
-                        float* dbeta, void* workspace, int64_t rows, int64_t cols, void* stream);
+                        float* dbeta, void* workspace, int64_t rows, int64_t cols, const float* beta_if_gelu_after,
+                        void* stream);   /* beta_if_gelu_after != null: dy is the gradient of gelu(LN(x)) (conv stack, HF:299) */
 int64_t aptai_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
 
 /* ------------------------------------------------------------------------------------------------ attention
@@ -133,14 +134,24 @@ int64_t aptai_colsum_workspace_bytes(int64_t rows, int64_t N);
 
 /* y = keep ? x/(1-p) : 0 with the counter mask of (seed, element index) — standalone nn.Dropout forward/backward */
 int aptai_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream);
+/* out = dy * gelu'(u) — backward of a standalone GELU (top of the conv stack, HF:267-272) */
+int aptai_dgelu_bf16(const void* dy, const void* u, void* out, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ conv layer 0
  * Conv1d(1,512,k=10,s=5) on the raw waveform fused with GroupNorm+GELU (mode 0, HF:302-323) or
  * bias+LayerNorm+GELU (mode 1, HF:275-299).  audio fp32 [B][S]; out bf16 [B][T_alloc][512], frames >= T_real zeroed. */
 int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias, const float* gamma,
                     const float* beta, int mode, float eps, void* out, int64_t T_real, int64_t T_alloc, int64_t C,
-                    int64_t Kw, int64_t stride, void* workspace, void* stream);
+                    int64_t Kw, int64_t stride, void* workspace, float* stats_out, void* stream);
 int64_t aptai_conv0_workspace_bytes(int64_t B, int64_t T_real);
+/* backward of the same fused layer: recomputes the conv from the waveform, folds GELU' and the GroupNorm / LayerNorm
+ * backward, and reduces dweight [512][10] (+ dbias, dgamma, dbeta) deterministically.  dy bf16 [B][T_alloc][512];
+ * fwd_stats fp32 [B][2][512] = (mean, rstd) written by the forward (`stats_out`), group mode only. */
+int aptai_conv0_bwd(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias, const float* gamma,
+                    const float* beta, int mode, float eps, const void* dy, int64_t T_real, int64_t T_alloc,
+                    const float* fwd_stats, float* dweight, float* dbias, float* dgamma, float* dbeta, void* workspace,
+                    void* stream);
+int64_t aptai_conv0_bwd_workspace_bytes(int64_t B, int64_t T_real);
 
 /* ------------------------------------------------------------------------------------------------ APTAI heads
  * a_tv = tanh(dropout(h)), a_ph = leaky_relu(dropout(h)) — the activations in front of the two head Linears

@@ -132,6 +132,36 @@ def test_aptai_base_arch_small():
     _run_case(cfg, seconds=1.3, B=3)
 
 
+def test_large_arch_trainable_conv_stack():
+    """LayerNorm conv stack (wav2vec2-large) with the feature encoder UNFROZEN: conv / LN gradients against the oracle."""
+    from aptai_amd.config import W2V2Config
+    from oracle import heads_ref, synth
+    cfg = W2V2Config.large(num_hidden_layers=2, hidden_dropout=0., activation_dropout=0., attention_dropout=0.,
+                           feat_proj_dropout=0., final_dropout=0., layerdrop=0., apply_spec_augment=False, vocab_size=46)
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), 0)
+    batch = synth.synth_aptai_batch(cfg, 2, 16000, seed=1234)
+    sdo = {k: v.clone().requires_grad_(True) if v.dtype == torch.float32 else v.clone() for k, v in sd.items()}
+    ref = heads_ref.aptai_forward(sdo, cfg, batch["audio_inputs"], batch["audio_lengths"], batch["phn_frames_49hz"],
+                                  [batch[n] for n in TV], training=True, tv_drop=0.0, phn_drop=0.0)
+    ref["loss"].backward()
+    model = _build(cfg, sd, tv_drop=0.0, phn_drop=0.0, freeze_feature_encoder=False)
+    model.train()
+    out = model(0, **{k: v.cuda() for k, v in batch.items()})
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    named = dict(model.named_parameters())
+    bad = []
+    for k, v in sdo.items():
+        if "feature_extractor" not in k or v.grad is None:
+            continue
+        gp = named[k].grad
+        assert gp is not None, k
+        r = _rel(gp.cpu(), v.grad)
+        if r > 0.1:
+            bad.append((k, round(r, 4)))
+    assert not bad, bad
+
+
 def test_aptai_golden_large_24_layers():
     """Against the reference's own outputs (models/aptai.py run on CPU, tests/golden/make_golden.py)."""
     from aptai_amd.config import W2V2Config
