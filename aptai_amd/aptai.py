@@ -25,56 +25,64 @@ from .wav2vec2 import Wav2Vec2Model, _seed
 _PADN = 64      # head Linears run on the MFMA GEMM with N padded to 64
 
 
-class _HeadsFn(torch.autograd.Function):
-    """tanh/leaky-relu -> Linear(H, n) x2 -> FIR -> masked MSE + masked CE (+ argmax), models/aptai.py:83-106."""
+def heads_fwd(h, tv_w, tv_b, ph_w, ph_b, st):
+    """tanh/leaky-relu -> Linear(H, n) x2 -> FIR -> masked MSE + masked CE (+ argmax), models/aptai.py:83-106.
+    Returns ((loss, mse, ce, tvs, pred, logits), saved)."""
+    g, M, H = st.g, st.g.M, h.shape[1]
+    dev = h.device
+    n_tv, n_phn = tv_w.shape[0], ph_w.shape[0]
+    a_tv, a_ph = ops.head_act_fwd(h, st.p_tv, st.p_ph, st.seed)
 
+    def pad_w(w, b):
+        wp = torch.zeros((_PADN, H), device=dev, dtype=torch.bfloat16)
+        ops.cast_bf16(w.detach(), wp[:w.shape[0]])
+        bp = torch.zeros(_PADN, device=dev, dtype=torch.float32)
+        bp[:b.shape[0]] = b.detach()
+        return wp, bp
+    wtv, btv = pad_w(tv_w, tv_b)
+    wph, bph = pad_w(ph_w, ph_b)
+    tv_raw = ops.gemm(a_tv, wtv, M, _PADN, H, bias=btv, out_f32=True)
+    logits = ops.gemm(a_ph, wph, M, _PADN, H, bias=bph, out_f32=True)
+    tvs = torch.empty((g.B, g.T, n_tv), device=dev, dtype=torch.float32)
+    ops.lowpass_fir(tv_raw, _PADN, g.Tp, st.taps, tvs, n_tv, g.T, g.B, g.T, g.T, n_tv, n_tv)
+    scalars, pred = ops.aptai_loss_fwd(tvs, st.tv_tgt, logits, _PADN, g.Tp, st.phn_tgt, g.B, g.T, n_tv, n_phn, st.w_mse, st.w_ce)
+    saved = SimpleNamespace(h=h, a_tv=a_tv, a_ph=a_ph, wtv=wtv, wph=wph, tvs=tvs, logits=logits, scalars=scalars, n_tv=n_tv,
+                            n_phn=n_phn)
+    return (scalars[0], scalars[1], scalars[2], tvs, pred, logits), saved
+
+
+def heads_bwd(s, st, gl):
+    """Returns (dh, dW_tv, db_tv, dW_ph, db_ph); ``gl`` = device scalar gradient of the loss (or None = 1)."""
+    g, M, H = st.g, st.g.M, s.h.shape[1]
+    d_tvs, d_logits = ops.aptai_loss_bwd(s.tvs, st.tv_tgt, s.logits, _PADN, g.Tp, st.phn_tgt, g.B, g.T, s.n_tv, s.n_phn, st.w_mse,
+                                         st.w_ce, s.scalars, gl, ldd=_PADN)
+    d_tvraw = torch.empty((M, _PADN), device=s.h.device, dtype=torch.bfloat16)
+    ops.lowpass_fir(d_tvs, s.n_tv, g.T, st.taps, d_tvraw, _PADN, g.Tp, g.B, g.T, g.Tp, s.n_tv, _PADN)
+    da_tv = ops.gemm(d_tvraw, s.wtv, M, H, _PADN, b_kmajor=True)
+    da_ph = ops.gemm(d_logits, s.wph, M, H, _PADN, b_kmajor=True)
+    sk = max(1, min(16, M // 1024))
+    dwtv = ops.gemm(d_tvraw, s.a_tv, _PADN, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk)
+    dwph = ops.gemm(d_logits, s.a_ph, _PADN, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk)
+    dbtv = ops.colsum(d_tvraw, M, _PADN)
+    dbph = ops.colsum(d_logits, M, _PADN)
+    dh = ops.head_act_bwd(s.h, da_tv, da_ph, st.p_tv, st.p_ph, st.seed)
+    return dh, dwtv[:s.n_tv], dbtv[:s.n_tv], dwph[:s.n_phn], dbph[:s.n_phn]
+
+
+class _HeadsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, tv_w, tv_b, ph_w, ph_b, st):
-        g, M, H = st.g, st.g.M, h.shape[1]
-        dev = h.device
-        n_tv, n_phn = tv_w.shape[0], ph_w.shape[0]
-        a_tv, a_ph = ops.head_act_fwd(h, st.p_tv, st.p_ph, st.seed)
-
-        def pad_w(w, b):
-            wp = torch.zeros((_PADN, H), device=dev, dtype=torch.bfloat16)
-            ops.cast_bf16(w.detach(), wp[:w.shape[0]])
-            bp = torch.zeros(_PADN, device=dev, dtype=torch.float32)
-            bp[:b.shape[0]] = b.detach()
-            return wp, bp
-        wtv, btv = pad_w(tv_w, tv_b)
-        wph, bph = pad_w(ph_w, ph_b)
-        tv_raw = ops.gemm(a_tv, wtv, M, _PADN, H, bias=btv, out_f32=True)
-        logits = ops.gemm(a_ph, wph, M, _PADN, H, bias=bph, out_f32=True)
-        tvs = torch.empty((g.B, g.T, n_tv), device=dev, dtype=torch.float32)
-        ops.lowpass_fir(tv_raw, _PADN, g.Tp, st.taps, tvs, n_tv, g.T, g.B, g.T, g.T, n_tv, n_tv)
-        scalars, pred = ops.aptai_loss_fwd(tvs, st.tv_tgt, logits, _PADN, g.Tp, st.phn_tgt, g.B, g.T, n_tv, n_phn,
-                                           st.w_mse, st.w_ce)
+        (loss, mse, ce, tvs, pred, logits), ctx.saved = heads_fwd(h, tv_w, tv_b, ph_w, ph_b, st)
         ctx.st = st
-        ctx.saved = SimpleNamespace(h=h, a_tv=a_tv, a_ph=a_ph, wtv=wtv, wph=wph, tvs=tvs, logits=logits, scalars=scalars,
-                                    n_tv=n_tv, n_phn=n_phn)
-        loss, mse, ce = scalars[0].clone(), scalars[1].clone(), scalars[2].clone()
+        loss, mse, ce = loss.clone(), mse.clone(), ce.clone()
         ctx.mark_non_differentiable(mse, ce, tvs, pred, logits)
         return loss, mse, ce, tvs, pred, logits
 
     @staticmethod
     def backward(ctx, gloss, *_):
-        st, s = ctx.st, ctx.saved
-        g, M, H = st.g, st.g.M, s.h.shape[1]
-        gl = gloss.float().reshape(1).contiguous()
-        d_tvs, d_logits = ops.aptai_loss_bwd(s.tvs, st.tv_tgt, s.logits, _PADN, g.Tp, st.phn_tgt, g.B, g.T, s.n_tv, s.n_phn,
-                                             st.w_mse, st.w_ce, s.scalars, gl, ldd=_PADN)
-        d_tvraw = torch.empty((M, _PADN), device=s.h.device, dtype=torch.bfloat16)
-        ops.lowpass_fir(d_tvs, s.n_tv, g.T, st.taps, d_tvraw, _PADN, g.Tp, g.B, g.T, g.Tp, s.n_tv, _PADN)
-        da_tv = ops.gemm(d_tvraw, s.wtv, M, H, _PADN, b_kmajor=True)
-        da_ph = ops.gemm(d_logits, s.wph, M, H, _PADN, b_kmajor=True)
-        sk = max(1, min(16, M // 1024))
-        dwtv = ops.gemm(d_tvraw, s.a_tv, _PADN, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk)
-        dwph = ops.gemm(d_logits, s.a_ph, _PADN, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk)
-        dbtv = ops.colsum(d_tvraw, M, _PADN)
-        dbph = ops.colsum(d_logits, M, _PADN)
-        dh = ops.head_act_bwd(s.h, da_tv, da_ph, st.p_tv, st.p_ph, st.seed)
+        out = heads_bwd(ctx.saved, ctx.st, gloss.float().reshape(1).contiguous())
         ctx.saved = None
-        return dh, dwtv[:s.n_tv], dbtv[:s.n_tv], dwph[:s.n_phn], dbph[:s.n_phn], None
+        return out + (None,)
 
 
 class APTAI(nn.Module):

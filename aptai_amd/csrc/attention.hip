@@ -32,6 +32,7 @@ struct AttnArgs {
     float c;                        // softmax_scale * log2(e)
     float scale;
     uint32_t seed0, seed1, thr16; float dscale;
+    const uint32_t* salt;
     // backward
     const bf16_t* dctx;
     const float* delta;
@@ -72,6 +73,7 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // ================================================================================== forward
 // grid (Tp/128, heads, B), 256 threads; wave w: queries q0 = qt*128 + w*32 .. +31
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+    if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];   // K tile, V tile (64 keys each)
     char* sK = smem;
     char* sV = smem + 64 * 128;
@@ -220,6 +222,7 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t*
 // ================================================================================== backward: dK, dV
 // grid (Tp/128, heads, B); wave w owns keys key0 = kt*128 + w*32 .. +31; loops over 32-query tiles.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
+    if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     __shared__ __attribute__((aligned(16))) char smem[2 * 32 * 128];   // Q tile, dO tile (32 queries each)
     char* sQ = smem;
     char* sD = smem + 32 * 128;
@@ -331,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 // ================================================================================== backward: dQ
 // grid (Tp/128, heads, B); wave w owns queries q0 = qt*128 + w*32 .. +31; loops over 32-key tiles.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+    if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     __shared__ __attribute__((aligned(16))) char smem[2 * 32 * 128];   // K tile, V tile (32 keys each)
     char* sK = smem;
     char* sV = smem + 32 * 128;
@@ -418,6 +422,7 @@ int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens
     a.scale = scale; a.c = scale * LOG2E;
     a.thr16 = drop_thr16(dropout_p); a.dscale = drop_scale(a.thr16);
     a.seed0 = (uint32_t)seed; a.seed1 = (uint32_t)(seed >> 32);
+    a.salt = aptai_seed_salt();
     return APTAI_OK;
 }
 

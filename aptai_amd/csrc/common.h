@@ -23,6 +23,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // ---------------------------------------------------------------------------------- error plumbing
 void aptai_set_error(const char* fmt, ...);
+const uint32_t* aptai_seed_salt(void);   // device pointer to the per-step dropout salt (or null), see runtime.hip
 #define APTAI_FAIL(code, ...)            \
     do {                                 \
         aptai_set_error(__VA_ARGS__);    \
@@ -115,6 +116,9 @@ __device__ __forceinline__ bool drop_keep(uint64_t e, uint32_t s0, uint32_t s1, 
 // both 16-bit lanes of the pair containing element e (e even)
 __device__ __forceinline__ uint32_t drop_hash_pair(uint64_t e, uint32_t s0, uint32_t s1) {
     return rng_hash((uint32_t)(e >> 1) ^ (uint32_t)(e >> 33) * 0x85ebca6bu, s0, s1);
+}
+__device__ __forceinline__ void apply_salt(const uint32_t* salt, uint32_t& s0, uint32_t& s1) {
+    if (salt) { s0 ^= salt[0]; s1 ^= salt[1]; }
 }
 static inline uint32_t drop_thr16(float p) {
     if (p <= 0.f) return 0;

@@ -160,7 +160,18 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     r1 = r1 < rows ? r1 : rows;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (col < N) {
-        for (long row = r0 + wave; row < r1; row += 4) {
+        long row = r0 + wave;
+        for (; row + 12 < r1; row += 16) {              // 4 independent 8-byte loads in flight per lane
+            const u32x2 p0 = *(const u32x2*)(x + row * ld + col);
+            const u32x2 p1 = *(const u32x2*)(x + (row + 4) * ld + col);
+            const u32x2 p2 = *(const u32x2*)(x + (row + 8) * ld + col);
+            const u32x2 p3 = *(const u32x2*)(x + (row + 12) * ld + col);
+            acc[0] += (lo_bf(p0[0]) + lo_bf(p1[0])) + (lo_bf(p2[0]) + lo_bf(p3[0]));
+            acc[1] += (hi_bf(p0[0]) + hi_bf(p1[0])) + (hi_bf(p2[0]) + hi_bf(p3[0]));
+            acc[2] += (lo_bf(p0[1]) + lo_bf(p1[1])) + (lo_bf(p2[1]) + lo_bf(p3[1]));
+            acc[3] += (hi_bf(p0[1]) + hi_bf(p1[1])) + (hi_bf(p2[1]) + hi_bf(p3[1]));
+        }
+        for (; row < r1; row += 4) {
             const u32x2 p = *(const u32x2*)(x + row * ld + col);
             acc[0] += lo_bf(p[0]); acc[1] += hi_bf(p[0]); acc[2] += lo_bf(p[1]); acc[3] += hi_bf(p[1]);
         }
@@ -193,7 +204,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // ---- APTAI head activations: a_tv = tanh(drop(h)), a_ph = leaky_relu(drop(h))   (models/aptai.py:43-55)
 __global__ void head_act_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ a_tv, bf16_t* __restrict__ a_ph,
                                     long n, uint32_t s0, uint32_t s1, uint32_t thr_tv, uint32_t thr_ph, float sc_tv,
-                                    float sc_ph) {
+                                    float sc_ph, const uint32_t* __restrict__ salt) {
+    if (thr_tv | thr_ph) apply_salt(salt, s0, s1);
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float x = bf2f(h[i]);
@@ -208,7 +220,9 @@ __global__ void head_act_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __rest
 // dh = d_tv * (1 - tanh^2) * mask_tv + d_ph * leaky' * mask_ph
 __global__ void head_act_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ d_tv,
                                     const bf16_t* __restrict__ d_ph, bf16_t* __restrict__ dh, long n, uint32_t s0,
-                                    uint32_t s1, uint32_t thr_tv, uint32_t thr_ph, float sc_tv, float sc_ph) {
+                                    uint32_t s1, uint32_t thr_tv, uint32_t thr_ph, float sc_tv, float sc_ph,
+                                    const uint32_t* __restrict__ salt) {
+    if (thr_tv | thr_ph) apply_salt(salt, s0, s1);
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float x = bf2f(h[i]);
@@ -223,7 +237,8 @@ __global__ void head_act_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* 
 
 // generic elementwise dropout apply (forward or backward): y = keep ? x*scale : 0
 __global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n, uint32_t s0, uint32_t s1,
-                               uint32_t thr, float sc) {
+                               uint32_t thr, float sc, const uint32_t* __restrict__ salt) {
+    apply_salt(salt, s0, s1);
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         y[i] = drop_keep((uint64_t)i, s0, s1, thr) ? f2bf(bf2f(x[i]) * sc) : (bf16_t)0;
@@ -325,7 +340,7 @@ extern "C" int aptai_frame_mask_bwd(void* dy, const int32_t* lens, const uint8_t
     return APTAI_OK;
 }
 
-static const int COLSUM_RPB = 256;
+static const int COLSUM_RPB = 128;
 extern "C" int64_t aptai_colsum_workspace_bytes(int64_t rows, int64_t N) { return ceil_div(rows, COLSUM_RPB) * N * 4; }
 extern "C" int aptai_colsum_bf16(const void* x, int64_t ld, float* out, void* workspace, int64_t rows, int64_t N,
                                  int accumulate, void* stream) {
@@ -346,7 +361,7 @@ extern "C" int aptai_head_act_fwd(const void* h, void* a_tv, void* a_ph, int64_t
     const uint32_t t1 = drop_thr16(p_tv), t2 = drop_thr16(p_ph);
     APTAI_LAUNCH(head_act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                        (bf16_t*)a_tv, (bf16_t*)a_ph, (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t1, t2, drop_scale(t1),
-                       drop_scale(t2));
+                       drop_scale(t2), aptai_seed_salt());
     APTAI_CHECK_LAUNCH("head_act_fwd_kernel");
     return APTAI_OK;
 }
@@ -357,7 +372,7 @@ extern "C" int aptai_head_act_bwd(const void* h, const void* d_tv, const void* d
     const uint32_t t1 = drop_thr16(p_tv), t2 = drop_thr16(p_ph);
     APTAI_LAUNCH(head_act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                        (const bf16_t*)d_tv, (const bf16_t*)d_ph, (bf16_t*)dh, (long)n, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       t1, t2, drop_scale(t1), drop_scale(t2));
+                       t1, t2, drop_scale(t1), drop_scale(t2), aptai_seed_salt());
     APTAI_CHECK_LAUNCH("head_act_bwd_kernel");
     return APTAI_OK;
 }
@@ -366,7 +381,7 @@ extern "C" int aptai_dropout_bf16(const void* x, void* y, int64_t n, float p, ui
     APTAI_REQUIRE(x && y && n > 0, "aptai_dropout_bf16: bad arguments");
     const uint32_t t = drop_thr16(p);
     APTAI_LAUNCH(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
-                       (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t, drop_scale(t));
+                       (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t, drop_scale(t), aptai_seed_salt());
     APTAI_CHECK_LAUNCH("dropout_kernel");
     return APTAI_OK;
 }

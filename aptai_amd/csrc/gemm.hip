@@ -37,6 +37,7 @@ struct GemmArgs {
     const bf16_t* aux; long ldaux;
     int flags;
     uint32_t seed0, seed1, thr16;
+    const uint32_t* salt;
     float dscale;
     float alpha;
     int ktiles_per_split;
@@ -224,10 +225,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
             for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
         }
         if (flags & APTAI_EPI_DROPOUT) {
+            uint32_t sd0 = g.seed0, sd1 = g.seed1;
+            apply_salt(g.salt, sd0, sd1);
             const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
 #pragma unroll
             for (int r = 0; r < 8; r += 2) {
-                const uint32_t hsh = drop_hash_pair(e + r, g.seed0, g.seed1);
+                const uint32_t hsh = drop_hash_pair(e + r, sd0, sd1);
                 v[r] = (hsh & 0xffffu) >= g.thr16 ? v[r] * g.dscale : 0.f;
                 v[r + 1] = (hsh >> 16) >= g.thr16 ? v[r + 1] * g.dscale : 0.f;
             }
@@ -508,10 +511,12 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
                 for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
             }
             if (flags & APTAI_EPI_DROPOUT) {
+                uint32_t sd0 = g.seed0, sd1 = g.seed1;
+                apply_salt(g.salt, sd0, sd1);
                 const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
 #pragma unroll
                 for (int r = 0; r < 8; r += 2) {
-                    const uint32_t hsh = drop_hash_pair(e + r, g.seed0, g.seed1);
+                    const uint32_t hsh = drop_hash_pair(e + r, sd0, sd1);
                     v[r] = (hsh & 0xffffu) >= g.thr16 ? v[r] * g.dscale : 0.f;
                     v[r + 1] = (hsh >> 16) >= g.thr16 ? v[r + 1] * g.dscale : 0.f;
                 }
@@ -586,6 +591,7 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux;
     g.flags = d->flags;
     g.seed0 = (uint32_t)d->seed; g.seed1 = (uint32_t)(d->seed >> 32);
+    g.salt = aptai_seed_salt();
     g.thr16 = drop_thr16(d->dropout_p);
     g.dscale = drop_scale(g.thr16);
     if (g.thr16 == 0) g.flags &= ~APTAI_EPI_DROPOUT;

@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ gamma, const bf16_t* __restrict__ dres,
                                                      bf16_t* __restrict__ dx, bf16_t* __restrict__ dx_drop,
                                                      uint32_t seed0, uint32_t seed1, uint32_t thr16, float dscale,
-                                                     float* __restrict__ partials, long rows, const float* __restrict__ beta_gelu) {
+                                                     float* __restrict__ partials, long rows, const float* __restrict__ beta_gelu,
+                                                     const uint32_t* __restrict__ salt) {
+    if (thr16) apply_salt(salt, seed0, seed1);
     constexpr int COLS = NCH * 256;
     __shared__ float red[4][2][COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
     }
 }
 
-constexpr int LN_BWD_MAX_BLOCKS = 256;
+constexpr int LN_BWD_MAX_BLOCKS = 512;
 
 }  // namespace
 
@@ -203,7 +205,7 @@ extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* m
     const uint32_t thr = drop_thr16(dropout_p);
     void* dxd = thr ? dx_drop : nullptr;
     if (dx_drop && !thr) APTAI_FAIL(APTAI_ERR_INVALID, "aptai_layernorm_bwd: dx_drop given with dropout_p == 0");
-#define LN_BWD(NCH) APTAI_LAUNCH(ln_bwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows, beta_if_gelu_after)
+#define LN_BWD(NCH) APTAI_LAUNCH(ln_bwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows, beta_if_gelu_after, aptai_seed_salt())
     switch (cols / 256) {
         case 1: LN_BWD(1); break;
         case 2: LN_BWD(2); break;

@@ -28,3 +28,13 @@ extern "C" int aptai_device_check(char* name, int name_len) {
         APTAI_FAIL(APTAI_ERR_NO_DEVICE, "device is %s; this library is built for gfx950 only", prop.gcnArchName);
     return APTAI_OK;
 }
+
+// Optional per-step salt for every dropout mask: a device pointer to two uint32 words that the seeded kernels XOR into
+// their (seed0, seed1).  Lets a captured hipGraph draw fresh masks on every replay (the host rewrites the two words
+// before the replay) while forward and backward of one step still regenerate identical masks.
+static const uint32_t* g_seed_salt = nullptr;
+extern "C" int aptai_set_seed_salt(const void* device_ptr_2xu32) {
+    g_seed_salt = (const uint32_t*)device_ptr_2xu32;
+    return APTAI_OK;
+}
+const uint32_t* aptai_seed_salt(void) { return g_seed_salt; }

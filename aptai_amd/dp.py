@@ -41,6 +41,7 @@ class GradBucketReducer:
         self._pending = [0] * len(self.buckets)
         self._handles = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._had_grad = [None] * len(self.buckets)
         self._hooks = []
         self._stream = None
         if self.world > 1:
@@ -78,6 +79,7 @@ class GradBucketReducer:
         for p in b:
             views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self._had_grad[bi] = [p.grad is not None for p in b]
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b]
         if flat.is_cuda:
             if self._stream is None:
@@ -107,15 +109,26 @@ class GradBucketReducer:
                 torch.cuda.current_stream().wait_stream(self._stream)
             off = 0
             outs, srcs = [], []
-            for p in b:
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                outs.append(p.grad)
-                srcs.append(flat[off:off + p.numel()].view_as(p))
+            for p, had in zip(b, self._had_grad[bi]):
+                # a parameter without a gradient on this rank has none on any rank (LayerDrop coins are shared): keep
+                # it None so the optimiser skips it exactly like the single-process reference
+                if had:
+                    outs.append(p.grad)
+                    srcs.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-            torch._foreach_copy_(outs, srcs)
-            torch._foreach_mul_(outs, inv)
+            if outs:
+                torch._foreach_copy_(outs, srcs)
+                torch._foreach_mul_(outs, inv)
         self.reset()
+
+    def reduce_existing_grads(self):
+        """For manually driven backward passes (aptai_amd.graphed): all-reduce whatever is in ``.grad`` right now."""
+        if self.world == 1:
+            return
+        self.reset()
+        for bi in range(len(self.buckets)):
+            self._launch(bi)
+        self.finish()
 
     def remove(self):
         for h in self._hooks:

@@ -1,0 +1,225 @@
+"""hipGraph-captured APTAI train step (HIP streams + graphs instead of a tracing compiler).
+
+The eager drop-in loop (``model(epoch, **batch)``; ``loss.backward()``; ``optimizer.step()``) issues ~1100 kernel
+launches per step from Python; on a loaded host that, not the GPU, sets the step time.  ``GraphedAPTAIStep`` captures
+the same kernels, through the same C ABI and the same fwd/bwd implementations the autograd path uses, into SEGMENT
+graphs:
+
+    prep (bf16 weight copies) | conv stack + encoder front | layer i forward ... | heads fwd+bwd | layer i backward ... | front bwd
+
+and replays them (~30 ``hipGraphLaunch`` per step).  Host-side randomness keeps the reference's semantics:
+ * LayerDrop (HF:701-703 / 774-776): a dropped layer's two graphs are simply not replayed (its activations / gradients are
+   forwarded by one device copy) and its parameters get ``grad = None`` that step, exactly like eager;
+ * SpecAugment (HF:101-217): the span mask is sampled on the host as before and copied into a static device buffer;
+ * dropout: kernels XOR a per-step device salt into their counter-RNG seeds (``aptai_set_seed_salt``), so every replay
+   draws fresh masks while the forward and backward of one step regenerate identical ones.
+The optimiser stays eager (torch's fused Adam: a handful of launches).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, hostlogic, ops
+from .aptai import APTAI, heads_bwd, heads_fwd
+from .wav2vec2 import _FinalLNImpl, _FrontImpl, _LayerImpl, _seed
+
+
+class GraphedAPTAIStep:
+    def __init__(self, model: APTAI, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], reducer=None):
+        assert model.training, "call model.train() first"
+        self.model, self.opt, self.reducer = model, optimizer, reducer
+        w = model.wav2vec2
+        self.w, self.cfg = w, w.config
+        cfg = self.cfg
+        dev = next(model.parameters()).device
+        self.dev = dev
+        if any(p.requires_grad for p in w.feature_extractor.parameters()):
+            raise NotImplementedError("GraphedAPTAIStep captures the frozen-feature-encoder configuration (APTAI's default)")
+        # ---- static inputs
+        self.audio = batch["audio_inputs"].float().contiguous().clone()
+        B, S = self.audio.shape
+        self.g = w._geometry(B, S)
+        g = self.g
+        self.lens_i32 = torch.zeros(B, device=dev, dtype=torch.int32)
+        self.spec = torch.zeros((B, g.T), device=dev, dtype=torch.uint8)
+        self.tv_tgt = torch.zeros((B, g.T, model.n_tv), device=dev, dtype=torch.float32)
+        self.phn_tgt = torch.zeros((B, g.T), device=dev, dtype=torch.int64)
+        self.salt = torch.zeros(2, device=dev, dtype=torch.int32)
+        self._salt_gen = np.random.RandomState(0xC0FFEE + w.base_seed)
+        _lib.call("aptai_set_seed_salt", self.salt.data_ptr())
+        self.set_batch(batch)
+        # one eager step first: allocates every persistent scratch buffer, loads the code objects and sets the kernel
+        # attributes outside of stream capture
+        model.zero_grad(set_to_none=True)
+        model(0, **batch)["loss"].backward()
+        model.zero_grad(set_to_none=True)
+        self._capture()
+
+    # ------------------------------------------------------------------ inputs
+    def set_batch(self, batch: Dict[str, torch.Tensor]) -> None:
+        cfg, g = self.cfg, self.g
+        self.audio.copy_(batch["audio_inputs"].float())
+        lens_cpu = batch["audio_lengths"].detach().cpu().long()
+        fl = hostlogic.feat_extract_output_lengths(lens_cpu, cfg.conv_kernel, cfg.conv_stride).clamp(min=1, max=g.T)
+        self.frame_lens_cpu = fl
+        self.lens_i32.copy_(fl.to(torch.int32))
+        tracks = [batch[k] for k in batch if k not in ("audio_inputs", "audio_lengths", "phn_frames_49hz", "phoneme_labels")]
+        self.tv_tgt.copy_(torch.stack(tracks, dim=-1).float())
+        self.phn_tgt.copy_(batch["phn_frames_49hz"])
+
+    def _host_randomness(self):
+        cfg, g = self.cfg, self.g
+        self.salt.copy_(torch.from_numpy(self._salt_gen.randint(-2 ** 31, 2 ** 31 - 1, size=2).astype(np.int32)))
+        if cfg.apply_spec_augment and cfg.mask_time_prob > 0:
+            am = torch.arange(g.T)[None, :] < self.frame_lens_cpu[:, None]
+            full = bool(am.all())
+            m = hostlogic.compute_mask_indices((g.B, g.T), cfg.mask_time_prob, cfg.mask_time_length,
+                                               attention_mask=None if full else am, min_masks=cfg.mask_time_min_masks)
+            self.spec.copy_(torch.from_numpy(m.astype(np.uint8)))
+        keep = [True] * cfg.num_hidden_layers
+        if cfg.layerdrop > 0:
+            keep = [float(torch.rand([], generator=self.w._layerdrop_gen)) >= cfg.layerdrop for _ in keep]
+        return keep
+
+    # ------------------------------------------------------------------ capture
+    def _capture(self):
+        model, w, cfg, g = self.model, self.w, self.cfg, self.g
+        L = cfg.num_hidden_layers
+        pool = torch.cuda.graph_pool_handle()
+        seed = _seed(w.base_seed, 0xABCD)
+        mk = torch.cuda.CUDAGraph
+        torch.cuda.synchronize()
+
+        # -- prep: every bf16 compute copy, rebuilt from the fp32 parameters on each replay
+        w._cache.clear()
+        w._cache_mode = "build"
+        self.g_prep = mk()
+        with torch.cuda.graph(self.g_prep, pool=pool):
+            w._conv_weights()
+            self.lw = [w._layer_weights(i, g.M) for i in range(L)]
+            fp, pc = w.feature_projection, w.encoder.pos_conv_embed.conv
+            w._cached(("proj",), [fp.projection.weight], lambda: ops.cast_bf16(fp.projection.weight))
+            w._cached(("posconv",), [pc.parametrizations.weight.original0, pc.parametrizations.weight.original1],
+                      lambda: ops.posconv_weight(pc.parametrizations.weight.original1,
+                                                 pc.parametrizations.weight.original0.reshape(-1),
+                                                 cfg.num_conv_pos_embedding_groups))
+        w._cache_mode = "frozen"
+
+        # -- front: conv stack (frozen) + projection + masking + positional conv (+ LN)
+        embed = getattr(w, "masked_spec_embed", None)
+        self.front = _FrontImpl(cfg, g, self.lens_i32, self.spec if embed is not None else None, True, _seed(seed, 1), w)
+        fp, pc = w.feature_projection, w.encoder.pos_conv_embed.conv
+        self.fparams = [fp.layer_norm.weight, fp.layer_norm.bias, fp.projection.weight, fp.projection.bias, embed,
+                        pc.parametrizations.weight.original0, pc.parametrizations.weight.original1, pc.bias,
+                        w.encoder.layer_norm.weight, w.encoder.layer_norm.bias]
+        self.g_front = mk()
+        with torch.cuda.graph(self.g_front, pool=pool):
+            feats = w._conv_forward(self.audio, g, save=False)[0]
+            (h,), self.s_front = self.front.fwd(feats, self.fparams, True)
+        self.X = [h]
+
+        # -- layers forward
+        self.impl, self.s_layer, self.g_fwd, self.lparams = [], [], [], []
+        for i, layer in enumerate(w.encoder.layers):
+            wt, lin = self.lw[i]
+            impl = _LayerImpl(cfg, g, self.lens_i32, wt, True, _seed(seed, 100 + i))
+            params = [layer.layer_norm.weight, layer.layer_norm.bias, layer.final_layer_norm.weight, layer.final_layer_norm.bias] + lin
+            gr = mk()
+            with torch.cuda.graph(gr, pool=pool):
+                (y,), s = impl.fwd(self.X[i], params, True)
+            self.impl.append(impl); self.s_layer.append(s); self.g_fwd.append(gr); self.lparams.append(params)
+            self.X.append(y)
+
+        # -- tail: [final LN] + heads forward + loss + heads backward + [final LN backward]
+        self.hparams = [model.tv_head[2].weight, model.tv_head[2].bias, model.phn_head[2].weight, model.phn_head[2].bias]
+        self.st_heads = SimpleNamespace(g=g, p_tv=model.tv_head[0].p, p_ph=model.phn_head[0].p, seed=_seed(seed, 999),
+                                        taps=model.tv_lowpass.taps(), tv_tgt=self.tv_tgt, phn_tgt=self.phn_tgt, w_mse=0.5, w_ce=0.5)
+        self.fin = _FinalLNImpl(cfg, g) if cfg.do_stable_layer_norm else None
+        self.g_tail = mk()
+        with torch.cuda.graph(self.g_tail, pool=pool):
+            hl = self.X[L]
+            if self.fin is not None:
+                (hl,), s_fin = self.fin.fwd(hl, [w.encoder.layer_norm.weight, w.encoder.layer_norm.bias], True)
+            self.outs, s_heads = heads_fwd(hl, *self.hparams, self.st_heads)
+            dh, *hgrads = heads_bwd(s_heads, self.st_heads, None)
+            fin_grads = []
+            if self.fin is not None:
+                dh, fin_grads = self.fin.bwd(s_fin, (dh,), True)
+        self.dX: List[Optional[torch.Tensor]] = [None] * (L + 1)
+        self.dX[L] = dh
+        self.grads: Dict[torch.nn.Parameter, torch.Tensor] = {}
+        for p, gt in zip(self.hparams, hgrads):
+            self.grads[p] = gt
+        if self.fin is not None:
+            self.grads[w.encoder.layer_norm.weight], self.grads[w.encoder.layer_norm.bias] = fin_grads
+
+        # -- layers backward (reverse capture order = replay order)
+        self.g_bwd = [None] * L
+        self.layer_grads = [None] * L
+        for i in range(L - 1, -1, -1):
+            gr = mk()
+            with torch.cuda.graph(gr, pool=pool):
+                dx, pg = self.impl[i].bwd(self.s_layer[i], (self.dX[i + 1],), True)
+            self.g_bwd[i] = gr
+            self.dX[i] = dx
+            self.layer_grads[i] = list(zip(self.lparams[i], pg))
+
+        # -- front backward
+        self.g_front_bwd = mk()
+        with torch.cuda.graph(self.g_front_bwd, pool=pool):
+            _, fg = self.front.bwd(self.s_front, (self.dX[0],), False)
+        for p, gt in zip(self.fparams, fg):
+            if p is not None and gt is not None:
+                self.grads[p] = gt
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ one optimiser step
+    def step(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        if batch is not None:
+            self.set_batch(batch)
+        keep = self._host_randomness()
+        L = self.cfg.num_hidden_layers
+        self.g_prep.replay()
+        self.g_front.replay()
+        for i in range(L):
+            if keep[i]:
+                self.g_fwd[i].replay()
+            else:
+                self.X[i + 1].copy_(self.X[i])
+        self.g_tail.replay()
+        for i in range(L - 1, -1, -1):
+            if keep[i]:
+                self.g_bwd[i].replay()
+            else:
+                self.dX[i].copy_(self.dX[i + 1])
+        self.g_front_bwd.replay()
+        for p, gt in self.grads.items():
+            if p.requires_grad:
+                p.grad = gt
+        for i in range(L):
+            for p, gt in self.layer_grads[i]:
+                if p.requires_grad:
+                    p.grad = gt if keep[i] else None
+        if self.reducer is not None:
+            self.reducer.reduce_existing_grads()
+        if not getattr(self, "_checked", False):
+            names = {id(p): n for n, p in self.model.named_parameters()}
+            for p in self.model.parameters():
+                if p.grad is not None and (p.grad.dtype != p.dtype or p.grad.shape != p.shape or not p.grad.is_contiguous()
+                                           or p.grad.device != p.device):
+                    raise RuntimeError(f"static gradient of {names[id(p)]} has dtype {p.grad.dtype} shape {tuple(p.grad.shape)} "
+                                       f"contiguous={p.grad.is_contiguous()} (parameter: {p.dtype} {tuple(p.shape)})")
+            self._checked = True
+        self.opt.step()
+        loss, mse, ce, tvs, pred, _ = self.outs
+        return {"loss": loss, "mse_loss": mse, "ce_loss": ce, "tvs_pred": tvs, "phn_fc_pred": pred}
+
+    def close(self):
+        """Back to the eager loop: drop the per-step salt and the frozen weight cache."""
+        _lib.call("aptai_set_seed_salt", None)
+        self.w._cache_mode = None
+        self.w._cache.clear()

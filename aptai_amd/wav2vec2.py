@@ -155,6 +155,8 @@ class _LayerImpl:
         return (y,), (s if need else None)
 
     def bwd(self, s, grads, x_needs):
+        """dgrad chain on the caller's stream; the weight/bias gradients (independent of that chain) go to a side stream
+        so their GEMMs fill the tails and epilogue phases of the dgrad GEMMs (256 CUs, 2 blocks each)."""
         cfg, g, w = self.cfg, self.g, self.w
         M, H, I = g.M, cfg.hidden_size, cfg.intermediate_size
         heads = cfg.num_attention_heads
@@ -163,6 +165,13 @@ class _LayerImpl:
         dy = grads[0].contiguous()
         pre = cfg.do_stable_layer_norm
         sk = w.split_k
+        main = torch.cuda.current_stream()
+        side = _side_stream(dy.device)
+
+        def on_side(fn):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                return fn()
         # ---- FFN block
         if pre:
             ds2 = dy                                             # y = s1 + D(ffn)
@@ -173,11 +182,11 @@ class _LayerImpl:
             if d_ffn_out is None:
                 d_ffn_out = ds2
             ffn_in = s.x1
-        dw2 = ops.gemm(d_ffn_out, s.hact, H, I, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[3])
-        dbias2 = ops.colsum(d_ffn_out, M, H)
+        dw2, dbias2 = on_side(lambda: (ops.gemm(d_ffn_out, s.hact, H, I, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[3]),
+                                       ops.colsum(d_ffn_out, M, H)))
         du = ops.gemm(d_ffn_out, w.w2, M, I, H, b_kmajor=True, dgelu_aux=s.u, dropout_p=p_a, seed=_seed(self.seed, 3))
-        dw1 = ops.gemm(du, ffn_in, I, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[2])
-        dbias1 = ops.colsum(du, M, I)
+        dw1, dbias1 = on_side(lambda: (ops.gemm(du, ffn_in, I, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[2]),
+                                       ops.colsum(du, M, I)))
         if pre:
             dn2 = ops.gemm(du, w.w1, M, H, I, b_kmajor=True)
             ds1, d_att_out, dg2, db2 = ops.layernorm_bwd(dn2, s.s1, s.m2, s.r2, ln2w, dres=ds2, dropout_p=p_h,
@@ -188,21 +197,33 @@ class _LayerImpl:
         if d_att_out is None:
             d_att_out = ds1
         # ---- attention block
-        dwo = ops.gemm(d_att_out, s.ctx, H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[1])
-        dbo = ops.colsum(d_att_out, M, H)
+        dwo, dbo = on_side(lambda: (ops.gemm(d_att_out, s.ctx, H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[1]),
+                                    ops.colsum(d_att_out, M, H)))
         dctx = ops.gemm(d_att_out, w.wo, M, H, H, b_kmajor=True)
         dqkv = ops.attention_bwd(s.qkv, self.lens, s.ctx, dctx, s.lse, g.B, g.Tp, H, heads, dropout_p=p_att,
                                  seed=_seed(self.seed, 1), dctx_zero_beyond_len=True)
         attn_in = s.n1 if pre else s.x
-        dwqkv = ops.gemm(dqkv, attn_in, 3 * H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[0])
-        dbqkv = ops.colsum(dqkv, M, 3 * H)
+        dwqkv, dbqkv = on_side(lambda: (ops.gemm(dqkv, attn_in, 3 * H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[0]),
+                                        ops.colsum(dqkv, M, 3 * H)))
         if pre:
             dn1 = ops.gemm(dqkv, w.wqkv, M, H, 3 * H, b_kmajor=True)
             dx, _, dg1, db1 = ops.layernorm_bwd(dn1, s.x, s.m1, s.r1, ln1w, dres=ds1)
         else:
             dx = ops.gemm(dqkv, w.wqkv, M, H, 3 * H, b_kmajor=True, residual=ds1)
+        main.wait_stream(side)
         return dx, (dg1, db1, dg2, db2, dwqkv[0:H], dwqkv[H:2 * H], dwqkv[2 * H:3 * H], dbqkv[0:H], dbqkv[H:2 * H],
                     dbqkv[2 * H:3 * H], dwo, dbo, dw1, dbias1, dw2, dbias2)
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[device] = st
+    return st
 
 
 # =================================================================================== front end of the encoder
@@ -292,7 +313,7 @@ class _FrontImpl:
         ops.gemm(dug[pad * Cg:], xg, Cg, K, kred, a_kmajor=True, b_kmajor=True, out_f32=True, lda=Cg, ldb=Cg, out=dwf, ldc=K,
                  batch=dict(outer=1, inner=G, a=(0, g.B * rows_p * Cg), b=(0, g.B * rows_p * Cg), c=(0, Cg * K)))
         # weight-norm backward (parameter-sized fp32 math): w = g * v / ||v||
-        dW = dwf.view(G, Cg, Kw, Cg).permute(0, 1, 3, 2).reshape(H, Cg, Kw)
+        dW = dwf.view(G, Cg, Kw, Cg).permute(0, 1, 3, 2).reshape(H, Cg, Kw).contiguous()
         v = pcv.detach()
         norm = s.norm.view(1, 1, Kw)
         gain = pcg.detach().view(1, 1, Kw)
@@ -460,9 +481,16 @@ class Wav2Vec2Model(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in params)
 
     def _cached(self, key, params, build):
+        mode = getattr(self, "_cache_mode", None)            # graph capture: "build" = always rebuild, "frozen" = always hit
+        if mode == "frozen":
+            return self._cache[key][1]
         ver = self._versions(params)
         hit = self._cache.get(key)
-        if hit is not None and hit[0] == ver:
+        # In training mode the copies are rebuilt on every forward: optimisers with fused kernels (e.g.
+        # torch.optim.Adam(fused=True)) update parameters in place WITHOUT bumping Tensor._version, so a version check
+        # would silently keep stale weights.  The casts are ~90 tiny launches per step.  Eval mode trusts the version.
+        trainable = self.training and any(p.requires_grad for p in params)
+        if mode != "build" and not trainable and hit is not None and hit[0] == ver:
             return hit[1]
         with torch.no_grad():
             val = build()
@@ -550,7 +578,15 @@ class Wav2Vec2Model(nn.Module):
         C = 512
         layer_mode = cfg.feat_extract_norm == "layer"
         sv = SimpleNamespace(bufs=[], pre=[None], stats=[None], audio=audio) if save else None
-        buf = torch.zeros((g.B * g.alloc[0] + 8, C), device=dev, dtype=torch.bfloat16)
+
+        def new_buf(i, rows):
+            # frozen path: persistent scratch (its slack rows were zeroed once); trainable path: fresh buffers (saved)
+            if save:
+                return torch.zeros((rows, C), device=dev, dtype=torch.bfloat16)
+            if i == len(cl) - 1:          # the features outlive this call (saved by the projection's backward): own storage
+                return torch.empty((rows, C), device=dev, dtype=torch.bfloat16)
+            return self._scratch(("conv", i, rows), rows * C, dev).view(rows, C)
+        buf = new_buf(0, g.B * g.alloc[0] + 8)
         l0 = cl[0]
         stats0 = ops.conv0_fwd(audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight,
                                l0.layer_norm.bias, 1 if layer_mode else 0, buf, g.Tl[0], g.alloc[0], want_stats=save)
@@ -561,7 +597,7 @@ class Wav2Vec2Model(nn.Module):
         for i in range(1, len(cl)):
             k, s = cfg.conv_kernel[i], cfg.conv_stride[i]
             Mi = g.B * g.alloc[i]
-            out = torch.zeros((Mi + 8, C), device=dev, dtype=torch.bfloat16)
+            out = new_buf(i, Mi + 8)
             bias = cl[i].conv.bias if cfg.conv_bias else None
             if layer_mode:
                 u = torch.zeros((Mi + 8, C), device=dev, dtype=torch.bfloat16) if save else out

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)
     ap.add_argument("--check-rmse", action="store_true", help="also report |RMSE_build - RMSE_oracle| on one small batch")
+    ap.add_argument("--eager", action="store_true", help="drive the step through autograd (the drop-in loop) instead of hipGraphs")
     return ap.parse_args()
 
 
@@ -161,14 +162,21 @@ def main():
     reducer = GradBucketReducer(params, bucket_mb=48.0, comm_dtype=torch.bfloat16) if world > 1 else None
     batch = synth_batch(cfg, B, S, args.n_tv, rank, device)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        out = model(0, **batch)
-        out["loss"].backward()
+    if args.eager:
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = model(0, **batch)
+            out["loss"].backward()
+            if reducer is not None:
+                reducer.finish()
+            opt.step()
+            return out
+    else:
+        from aptai_amd.graphed import GraphedAPTAIStep
         if reducer is not None:
-            reducer.finish()
-        opt.step()
-        return out
+            reducer.remove()                 # gradients are reduced explicitly after the captured backward
+        runner = GraphedAPTAIStep(model, opt, batch, reducer=reducer)
+        step = runner.step
 
     for _ in range(args.warmup):
         step()
@@ -186,6 +194,19 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     ops.set_gemm_probe(None)
+    probe_note = "HIP events around every launch inside the timed region"
+    if not args.eager:
+        # kernels inside a hipGraph replay cannot be bracketed one by one: re-issue the SAME step eagerly right after the
+        # timed region (same model, batch, shapes, regularisers) with the event probe on
+        runner.close()
+        probe = ops.GemmProbe(False, False, False)
+        ops.set_gemm_probe(probe)
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            model(0, **batch)["loss"].backward()
+        torch.cuda.synchronize()
+        ops.set_gemm_probe(None)
+        probe_note = "HIP events around every launch of 3 eager re-runs of the same step right after the timed region"
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,12 +230,13 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "clip_seconds": args.seconds,
                        "frames_per_clip": int(S // 320 - (1 if S % 320 < 80 else 0)) if False else None,
                        "parallelism": f"dp{world}", "regularisers": "off" if args.no_regularisers else "HF defaults",
-                       "optimizer": "Adam (torch fused, fp32 state)"},
+                       "optimizer": "Adam (torch fused, fp32 state)",
+                       "execution": "eager autograd loop" if args.eager else "hipGraph segments (aptai_amd.graphed)"},
             "loss": round(loss, 5),
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<NT> (bf16 MFMA 16x16x32, all launches in the timed region)",
                          "achieved": round(gemm_tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / 2500.0, 4), "traffic": None,
-                         "launches": ps["launches"], "avg_launch_us": round(ps["ms"] * 1e3 / max(ps["launches"], 1), 2),
+                         "measured": probe_note, "launches": ps["launches"], "avg_launch_us": round(ps["ms"] * 1e3 / max(ps["launches"], 1), 2),
                          "step_algorithmic_tflop": step_tf,
                          "whole_step_frac_of_peak": round(step_tf / (dt / args.steps) / 2500.0, 4) if step_tf else None},
         }

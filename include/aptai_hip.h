@@ -32,6 +32,9 @@ const char* aptai_last_error(void);
 int aptai_version(void);
 /* device sanity: returns APTAI_OK iff a gfx950 device is current; fills name (<=63 chars) if non-null */
 int aptai_device_check(char* name, int name_len);
+/* Per-step dropout salt: device pointer to two uint32 words XORed into every kernel's dropout seed (null = off).
+ * A captured hipGraph thereby draws fresh masks on each replay; forward and backward of one step stay consistent. */
+int aptai_set_seed_salt(const void* device_ptr_2xu32);
 
 /* ------------------------------------------------------------------------------------------------ GEMM
  * C[M,N] = A . B^T with fp32 accumulation (MFMA), replacing nn.Linear / nn.Conv1d(k>1 as implicit GEMM):

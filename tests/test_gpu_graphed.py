@@ -1,0 +1,98 @@
+"""GPU: the hipGraph-captured train step replays the same kernels as the eager autograd loop — with all stochastic
+regularisers at 0 the losses and the updated parameters of the two paths agree after several optimiser steps."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_graphed_step_matches_eager():
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.graphed import GraphedAPTAIStep
+    from oracle import synth
+    from test_gpu_aptai import _build
+    cfg = W2V2Config.base(num_hidden_layers=3, hidden_dropout=0., activation_dropout=0., attention_dropout=0.,
+                          feat_proj_dropout=0., final_dropout=0., layerdrop=0., apply_spec_augment=False, vocab_size=46)
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), 0)
+    batch = {k: v.cuda() for k, v in synth.synth_aptai_batch(cfg, 2, 16000, seed=3).items()}
+    losses = {}
+    finals = {}
+    for mode in ("eager", "graph"):
+        model = _build(cfg, sd, tv_drop=0.0, phn_drop=0.0)
+        model.train()
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+        ls = []
+        if mode == "eager":
+            for _ in range(4):
+                opt.zero_grad(set_to_none=True)
+                out = model(0, **batch)
+                out["loss"].backward()
+                opt.step()
+                ls.append(out["loss"].item())
+        else:
+            runner = GraphedAPTAIStep(model, opt, batch)
+            for _ in range(4):
+                ls.append(runner.step()["loss"].item())
+            runner.close()
+        losses[mode] = ls
+        finals[mode] = {n: p.detach().float().cpu().clone() for n, p in model.named_parameters()}
+    assert losses["eager"][-1] < losses["eager"][0]                    # it trains
+    for a, b in zip(losses["eager"], losses["graph"]):
+        assert abs(a - b) <= 2e-3 * abs(a), (losses["eager"], losses["graph"])
+    for n in finals["eager"]:
+        d = (finals["eager"][n] - finals["graph"][n]).abs().max().item()
+        assert d <= 2e-4, (n, d)                                          # lr 1e-4 x 4 steps: updates are <= 4e-4
+
+
+def test_graphed_step_with_regularisers_runs_and_varies():
+    """LayerDrop / SpecAugment / dropout active: replays draw fresh randomness (loss differs step to step), stays finite,
+    and dropped layers' parameters get no gradient."""
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.graphed import GraphedAPTAIStep
+    from oracle import synth
+    from test_gpu_aptai import _build
+    cfg = W2V2Config.base(num_hidden_layers=4, layerdrop=0.5, vocab_size=46)
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), 0)
+    batch = {k: v.cuda() for k, v in synth.synth_aptai_batch(cfg, 2, 16000, seed=3).items()}
+    model = _build(cfg, sd)
+    model.train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.0, fused=True)
+    runner = GraphedAPTAIStep(model, opt, batch)
+    ls, dropped_seen = [], False
+    for _ in range(6):
+        out = runner.step()
+        ls.append(out["loss"].item())
+        for layer in model.wav2vec2.encoder.layers:
+            if layer.attention.q_proj.weight.grad is None:
+                dropped_seen = True
+    runner.close()
+    assert all(torch.isfinite(torch.tensor(ls))) and len(set(round(x, 6) for x in ls)) > 1, ls
+    assert dropped_seen
+
+
+def test_eager_loop_sees_fused_optimizer_updates():
+    """torch.optim.Adam(fused=True) updates parameters without bumping Tensor._version: the bf16 compute copies must
+    still follow (regression test for a stale-weight bug)."""
+    from aptai_amd.config import W2V2Config
+    from oracle import heads_ref, synth
+    from test_gpu_aptai import _build, TV
+    cfg = W2V2Config.base(num_hidden_layers=2, hidden_dropout=0., activation_dropout=0., attention_dropout=0.,
+                          feat_proj_dropout=0., final_dropout=0., layerdrop=0., apply_spec_augment=False, vocab_size=46)
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), 0)
+    cb = synth.synth_aptai_batch(cfg, 2, 16000, seed=3)
+    batch = {k: v.cuda() for k, v in cb.items()}
+    model = _build(cfg, sd, tv_drop=0.0, phn_drop=0.0)
+    model.train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3e-4, fused=True)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        model(0, **batch)["loss"].backward()
+        opt.step()
+    got = model(0, **batch)["loss"].item()
+    sdc = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = heads_ref.aptai_forward(sdc, cfg, cb["audio_inputs"], cb["audio_lengths"], cb["phn_frames_49hz"], [cb[n] for n in TV],
+                                  training=False)["loss"].item()
+    assert abs(got - ref) <= 2e-2 * abs(ref), (got, ref)
