@@ -170,8 +170,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
     }
 
     // ------------------------------------------------------------------ epilogue
+    // Phase 0: issue the residual / aux row loads of ALL 8 passes now (16 B each): their HBM latency hides under the
+    //          LDS staging instead of serialising pass after pass.
     // Phase 1: accumulators -> fp32 LDS tile [128][128] (row pitch 528 B: conflict-free 16-B writes of 16 rows).
     // acc[i][j][r]: m = wm*64 + i*16 + (lane&15);  n = wn*64 + j*16 + (lane>>4)*4 + r
+    const int flags = g.flags;
+    const int cl = (tid & 15) * 8;                     // column inside the tile, fixed per thread
+    const int n = n0 + cl;
+    const bool n_ok = n < g.N;
+    u32x4 resv[8], auxv[8];
+    if (!OUT_F32) {
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int m = m0 + pass * 16 + (tid >> 4);
+            const bool ok = n_ok && m < g.M;
+            resv[pass] = (u32x4){0u, 0u, 0u, 0u};
+            auxv[pass] = (u32x4){0u, 0u, 0u, 0u};
+            if (ok && (flags & APTAI_EPI_RESIDUAL)) resv[pass] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+            if (ok && (flags & APTAI_EPI_DGELU)) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+        }
+    }
     __syncthreads();                                   // every wave is done reading the staging buffers
     {
         char* ct = smem;
@@ -188,10 +206,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
     __syncthreads();
     // Phase 2: thread -> 8 consecutive columns of one row per pass (16 threads cover a 512-B row): every global
     // access of the epilogue (residual, aux, out_pre, C) is a coalesced 16/32-byte-per-lane row segment.
-    const int flags = g.flags;
-    const int cl = (tid & 15) * 8;                     // column inside the tile, fixed per thread
-    const int n = n0 + cl;
-    const bool n_ok = n < g.N;
     float bias8[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) bias8[r] = 0.f;
@@ -201,7 +215,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
         for (int r = 0; r < 4; ++r) { bias8[r] = b0[r]; bias8[4 + r] = b1[r]; }
     }
     const float alpha = (flags & APTAI_EPI_ALPHA) ? g.alpha : 1.0f;
-#pragma unroll 2
+    uint32_t sd0 = g.seed0, sd1 = g.seed1;
+    if (flags & APTAI_EPI_DROPOUT) apply_salt(g.salt, sd0, sd1);
+#pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
         const int ml = pass * 16 + (tid >> 4);
         const int m = m0 + ml;
@@ -225,8 +241,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
             for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
         }
         if (flags & APTAI_EPI_DROPOUT) {
-            uint32_t sd0 = g.seed0, sd1 = g.seed1;
-            apply_salt(g.salt, sd0, sd1);
             const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
 #pragma unroll
             for (int r = 0; r < 8; r += 2) {
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
             }
         }
         if (flags & APTAI_EPI_DGELU) {
-            const u32x4 a = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+            const u32x4 a = auxv[pass];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[2 * r] *= gelu_fast_grad(lo_bf(a[r]));
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
             }
         }
         if (flags & APTAI_EPI_RESIDUAL) {
-            const u32x4 a = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+            const u32x4 a = resv[pass];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[2 * r] += lo_bf(a[r]); v[2 * r + 1] += hi_bf(a[r]); }
         }

@@ -155,8 +155,8 @@ class _LayerImpl:
         return (y,), (s if need else None)
 
     def bwd(self, s, grads, x_needs):
-        """dgrad chain on the caller's stream; the weight/bias gradients (independent of that chain) go to a side stream
-        so their GEMMs fill the tails and epilogue phases of the dgrad GEMMs (256 CUs, 2 blocks each)."""
+        """dgrad chain on the caller's stream; the weight/bias gradients are independent of that chain and can go to a side
+        stream (APTAI_SIDE_STREAM=1).  Off by default: each GEMM already fills the 256 CUs, the A/B was neutral."""
         cfg, g, w = self.cfg, self.g, self.w
         M, H, I = g.M, cfg.hidden_size, cfg.intermediate_size
         heads = cfg.num_attention_heads
@@ -169,6 +169,8 @@ class _LayerImpl:
         side = _side_stream(dy.device)
 
         def on_side(fn):
+            if not _USE_SIDE_STREAM:
+                return fn()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 return fn()
@@ -216,6 +218,7 @@ class _LayerImpl:
 
 
 _SIDE_STREAMS = {}
+_USE_SIDE_STREAM = os.environ.get("APTAI_SIDE_STREAM", "0") != "0"     # measured neutral on MI355X (A/B 15.95 vs 15.98 ms/step)
 
 
 def _side_stream(device):
