@@ -216,6 +216,14 @@ def main():
         print(f"[bench] timed region: {dt / args.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
         ps = probe.summary()
         gemm_tflops = ps["flops"] / (ps["ms"] * 1e-3) / 1e12 if ps["ms"] > 0 else 0.0
+        traffic = None
+        try:                 # PMC traffic of the dominant kernel, collected offline (tools/pmc_summary.py), bytes per launch
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            for k, v in pm.items():
+                if "gemm_kernel<false, false, false>" in k:
+                    traffic = v["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            pass
         gf = FWD_GF.get((args.model, args.seconds))
         step_tf = None
         if gf:
@@ -233,9 +241,11 @@ def main():
                        "optimizer": "Adam (torch fused, fp32 state)",
                        "execution": "eager autograd loop" if args.eager else "hipGraph segments (aptai_amd.graphed)"},
             "loss": round(loss, 5),
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<NT> (bf16 MFMA 16x16x32, all launches in the timed region)",
+            "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM, NT layout (gemm_kernel<false,false,false> + gemm256_kernel<false,false,false>): every launch of the step",
                          "achieved": round(gemm_tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / 2500.0, 4), "traffic": None,
+                         "frac": round(gemm_tflops / 2500.0, 4), "traffic": traffic,
+                         "traffic_note": "HBM-side bytes per launch, rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, separate passes), "
+                                         "profiles/r01_pmc_traffic.json",
                          "measured": probe_note, "launches": ps["launches"], "avg_launch_us": round(ps["ms"] * 1e3 / max(ps["launches"], 1), 2),
                          "step_algorithmic_tflop": step_tf,
                          "whole_step_frac_of_peak": round(step_tf / (dt / args.steps) / 2500.0, 4) if step_tf else None},
