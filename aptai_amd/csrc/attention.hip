@@ -40,24 +40,34 @@ struct AttnArgs {
     int skip_pad_q;
 };
 
-// ---- LDS tile [rows][64] bf16, 128-B rows, 16-B chunk index XORed with (row & 7)
+// ---- LDS tile [rows][64] bf16, 128-B rows, 16-B chunk index XORed with (row & 7).
+// All per-lane LDS offsets are loop invariant and are computed ONCE per kernel (the per-tile instruction count, not the
+// MFMA rate, is what bounds these kernels at T ~ 500: every VALU instruction in the tile loop costs ~1/500 of it).
 __device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-__device__ __forceinline__ bf16x8 frag_row(const char* tile, int row, int chunk) {
-    return *(const bf16x8*)(tile + tile_off(row, chunk));
+struct LaneOffs {
+    int rowk[4];      // row reads: byte offset of this lane's 16-B chunk for d-step ds (tile row = lane&31); + row_block*4096
+    int tr[2];        // transposed reads: byte offset for d-tile dt, depth block 0 (rows 4h+qq); + s*2048 (+1024 for the hi half)
+};
+__device__ __forceinline__ LaneOffs lane_offs(int lane) {
+    LaneOffs o;
+    const int r31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) o.rowk[ds] = r31 * 128 + (((2 * ds + h) ^ (r31 & 7)) << 4);
+    const int dgrp = (lane >> 4) & 1, i = lane & 15, qq = i >> 2, p = i & 3;
+    const int trow = 4 * h + qq;                          // (16*s + trow) & 7 == trow & 7, also for the +8 half
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) o.tr[dt] = trow * 128 + (((dt * 4 + 2 * dgrp + (p >> 1)) ^ (trow & 7)) << 4) + ((p & 1) << 3);
+    return o;
 }
-
-// A operand (rows = tile columns d, depth = tile rows) for 32x32x16: element j <-> tile row
-// rbase + 8*(j>>2) + 4*h + (j&3)   (h = lane>>5), matching the accumulator-as-operand k order.
-__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int rbase, int dt, int lane) {
-    const int dgrp = (lane >> 4) & 1, h = lane >> 5, i = lane & 15, qq = i >> 2, p = i & 3;
-    const int ch = dt * 4 + 2 * dgrp + (p >> 1);
-    const int sub = (p & 1) << 3;
-    const int r_lo = rbase + 4 * h + qq, r_hi = r_lo + 8;
-    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) short4v*)(tile + tile_off(r_lo, ch) + sub));
-    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) short4v*)(tile + tile_off(r_hi, ch) + sub));
+__device__ __forceinline__ bf16x8 rd_row(const char* tile, const LaneOffs& o, int row_block, int ds) {
+    return *(const bf16x8*)(tile + o.rowk[ds] + row_block * 4096);
+}
+// A operand (rows = tile columns d, depth = tile rows) for 32x32x16: element j <-> tile row 16*s + 8*(j>>2) + 4*h + (j&3)
+__device__ __forceinline__ bf16x8 rd_tr(const char* tile, const LaneOffs& o, int s, int dt) {
+    const char* p0 = tile + o.tr[dt] + s * 2048;
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p0);
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p0 + 1024));
     short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, r);
 }
@@ -70,13 +80,19 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 // accumulator register r of a 32x32 tile <-> row (r&3) + 8*(r>>2) + 4*h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// dropout on P: one hash per PAIR of consecutive keys of one query row; pair index = (bh*Tp + q)*(Tp/2) + key/2 (32-bit)
+__device__ __forceinline__ bool attn_keep(uint32_t pair, int key, uint32_t s0, uint32_t s1, uint32_t thr16) {
+    const uint32_t hsh = rng_hash(pair, s0, s1);
+    return ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= thr16;
+}
+
 // ================================================================================== forward
 // grid (Tp/128, heads, B), 256 threads; wave w: queries q0 = qt*128 + w*32 .. +31
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
-    if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];   // K tile, V tile (64 keys each)
     char* sK = smem;
     char* sV = smem + 64 * 128;
+    if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = blockIdx.z, hd = blockIdx.y;
     const int q0 = blockIdx.x * 128 + wave * 32;
@@ -84,9 +100,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     len = len < 1 ? 1 : (len > a.Tp ? a.Tp : len);
     const int ntiles = (len + 63) >> 6;
     const long rowbase = (long)b * a.Tp;
-    const bf16_t* Qg = a.qkv + (rowbase + q0 + (lane & 31)) * a.ld + hd * HD;
+    const int q = q0 + (lane & 31);
+    const bf16_t* Qg = a.qkv + (rowbase + q) * a.ld + hd * HD;
     const bf16_t* Kg = a.qkv + rowbase * a.ld + a.H + hd * HD;
     const bf16_t* Vg = Kg + a.H;
+    const LaneOffs lo = lane_offs(lane);
 
     bf16x8 qf[4];
 #pragma unroll
@@ -95,79 +113,84 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     f32x16 oT[2];
     oT[0] = (f32x16)(0.f);
     oT[1] = (f32x16)(0.f);
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;      // running max in the RAW score domain, running sum in the exp2 domain
 
-    // staging registers: 512 chunks per tile, 2 per thread per tensor
+    // staging: 512 16-B chunks per tile, 2 per thread per tensor; offsets are loop invariant
+    int soff[2];
+    long goff[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int cid = it * 256 + tid, row = cid >> 3, ch = cid & 7;
+        soff[it] = tile_off(row, ch);
+        goff[it] = (long)row * a.ld + ch * 8;
+    }
     u32x4 kreg[2], vreg[2];
-    auto load_tile = [&](int t) {
+    const long tile_stride = 64 * a.ld;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int cid = it * 256 + tid, row = cid >> 3, ch = cid & 7;
-            const long g = (long)(t * 64 + row) * a.ld + ch * 8;
-            kreg[it] = *(const u32x4*)(Kg + g);
-            vreg[it] = *(const u32x4*)(Vg + g);
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int cid = it * 256 + tid, row = cid >> 3, ch = cid & 7;
-            *(u32x4*)(sK + tile_off(row, ch)) = kreg[it];
-            *(u32x4*)(sV + tile_off(row, ch)) = vreg[it];
-        }
-    };
-    load_tile(0);
-    const uint64_t ebase = ((uint64_t)(b * a.heads + hd) * a.Tp + (uint64_t)(q0 + (lane & 31))) * (uint64_t)a.Tp;
+    for (int it = 0; it < 2; ++it) { kreg[it] = *(const u32x4*)(Kg + goff[it]); vreg[it] = *(const u32x4*)(Vg + goff[it]); }
+    const uint32_t pbase = (uint32_t)(((b * a.heads + hd) * a.Tp + q) * (a.Tp >> 1));
+    const float c = a.c;
 
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
-        store_tile();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) { *(u32x4*)(sK + soff[it]) = kreg[it]; *(u32x4*)(sV + soff[it]) = vreg[it]; }
         __syncthreads();
-        if (t + 1 < ntiles) load_tile(t + 1);
-
+        if (t + 1 < ntiles) {
+            const bf16_t* kn = Kg + (long)(t + 1) * tile_stride;
+            const bf16_t* vn = Vg + (long)(t + 1) * tile_stride;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) { kreg[it] = *(const u32x4*)(kn + goff[it]); vreg[it] = *(const u32x4*)(vn + goff[it]); }
+        }
         // S^T tiles: keys (kt2*32 + acc_row) x queries (lane&31)
         f32x16 sT[2];
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2) {
-            sT[kt2] = (f32x16)(0.f);
+            sT[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sK, lo, kt2, 0), qf[0], (f32x16)(0.f), 0, 0, 0);
 #pragma unroll
-            for (int ds = 0; ds < 4; ++ds) {
-                const bf16x8 kf = frag_row(sK, kt2 * 32 + (lane & 31), 2 * ds + h);
-                sT[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sT[kt2], 0, 0, 0);
-            }
+            for (int ds = 1; ds < 4; ++ds)
+                sT[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sK, lo, kt2, ds), qf[ds], sT[kt2], 0, 0, 0);
         }
-        // online softmax in the exp2 domain
-        float x[2][16];
-        float mt = -INFINITY;
         const int kbase = t * 64;
+        if (kbase + 64 > len) {                               // boundary tile only: mask keys >= len (wave-uniform branch)
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2)
+            for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + kt2 * 32 + acc_row(r, h);
-                const float v = key < len ? sT[kt2][r] * a.c : -INFINITY;
-                x[kt2][r] = v;
-                mt = fmaxf(mt, v);
-            }
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + kt2 * 32 + acc_row(r, h) >= len) sT[kt2][r] = -INFINITY;
+        }
+        float mt = sT[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sT[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sT[1][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = fast_exp2((m_run - m_new) * c);
+        const float mc = m_new * c;
         m_run = m_new;
+        float x[2][16];
         float psum = 0.f;
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(x[kt2][r] - m_new);
+                const float p = fast_exp2(fmaf(sT[kt2][r], c, -mc));
                 psum += p;
-                float pd = p;
-                if (a.thr16) {
-                    const int key = kbase + kt2 * 32 + acc_row(r, h);
-                    pd = drop_keep(ebase + key, a.seed0, a.seed1, a.thr16) ? p * a.dscale : 0.f;
-                }
-                x[kt2][r] = pd;
+                x[kt2][r] = p;
             }
-        l_run = l_run * alpha + psum;
+        if (a.thr16) {
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {              // registers r, r+1 are consecutive keys: one hash per pair
+                    const int key = kbase + kt2 * 32 + acc_row(r, h);
+                    const uint32_t hsh = rng_hash(pbase + (uint32_t)(key >> 1), a.seed0, a.seed1);
+                    x[kt2][r] = (hsh & 0xffffu) >= a.thr16 ? x[kt2][r] * a.dscale : 0.f;
+                    x[kt2][r + 1] = (hsh >> 16) >= a.thr16 ? x[kt2][r + 1] * a.dscale : 0.f;
+                }
+        }
+        l_run = fmaf(l_run, alpha, psum);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oT[0][r] *= alpha; oT[1][r] *= alpha; }
         // O^T += V^T P^T : 4 k-steps of 16 keys
@@ -175,45 +198,53 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int s = 0; s < 4; ++s) {
             const bf16x8 pf = pack8(&x[s >> 1][8 * (s & 1)]);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 vf = frag_tr(sV, 16 * s, dt, lane);
-                oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oT[dt], 0, 0, 0);
-            }
+            for (int dt = 0; dt < 2; ++dt)
+                oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(sV, lo, s, dt), pf, oT[dt], 0, 0, 0);
         }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int q = q0 + (lane & 31);
+    const float inv = __frcp_rn(l_tot);
     bf16_t* og = a.ctx + (rowbase + q) * a.ldo + hd * HD;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = dt * 32 + 8 * g4 + 4 * h;
-            u32x2 o = {pack2bf(oT[dt][4 * g4 + 0] * inv, oT[dt][4 * g4 + 1] * inv),
-                       pack2bf(oT[dt][4 * g4 + 2] * inv, oT[dt][4 * g4 + 3] * inv)};
-            *(u32x2*)(og + d) = o;
-            if (a.o32)
-                *(f32x4*)(a.o32 + (rowbase + q) * a.ldo + hd * HD + d) =
-                    (f32x4){oT[dt][4 * g4 + 0] * inv, oT[dt][4 * g4 + 1] * inv, oT[dt][4 * g4 + 2] * inv, oT[dt][4 * g4 + 3] * inv};
+            const float o0 = oT[dt][4 * g4 + 0] * inv, o1 = oT[dt][4 * g4 + 1] * inv, o2 = oT[dt][4 * g4 + 2] * inv,
+                        o3 = oT[dt][4 * g4 + 3] * inv;
+            *(u32x2*)(og + d) = (u32x2){pack2bf(o0, o1), pack2bf(o2, o3)};
+            if (a.o32) *(f32x4*)(a.o32 + (rowbase + q) * a.ldo + hd * HD + d) = (f32x4){o0, o1, o2, o3};
         }
-    if (a.lse2 && h == 0) a.lse2[((long)b * a.heads + hd) * a.Tp + q] = m_run + log2f(l_tot);
+    if (a.lse2 && h == 0) a.lse2[((long)b * a.heads + hd) * a.Tp + q] = fmaf(m_run, c, fast_log2(l_tot));
 }
 
 // ================================================================================== delta = rowsum(dO * O)
-// one wave per (row, head): 64 elements
+// 8 lanes per (row, head): 8 elements each (16-B bf16 + 32-B fp32 loads), shuffle-reduce inside the 8-lane group
 __global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx, const float* __restrict__ o32,
                                   float* __restrict__ delta, int B, int Tp, int H, int heads) {
-    const long gw = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long item = gid >> 3;                               // (row, head)
+    const int sub = (int)(gid & 7);
     const long total = (long)B * Tp * heads;
-    if (gw >= total) return;
-    const long row = gw / heads;
-    const int hd = (int)(gw % heads);
-    const long off = row * H + hd * HD + lane;
-    float v = bf2f(dctx[off]) * (o32 ? o32[off] : bf2f(ctx[off]));
-    v = wave_sum(v);
-    if (lane == 0) {
+    if (item >= total) return;
+    const long row = item / heads;
+    const int hd = (int)(item % heads);
+    const long off = row * H + hd * HD + sub * 8;
+    const u32x4 d = *(const u32x4*)(dctx + off);
+    float v = 0.f;
+    if (o32) {
+        const f32x4 a0 = *(const f32x4*)(o32 + off), a1 = *(const f32x4*)(o32 + off + 4);
+        v = lo_bf(d[0]) * a0[0] + hi_bf(d[0]) * a0[1] + lo_bf(d[1]) * a0[2] + hi_bf(d[1]) * a0[3] + lo_bf(d[2]) * a1[0] +
+            hi_bf(d[2]) * a1[1] + lo_bf(d[3]) * a1[2] + hi_bf(d[3]) * a1[3];
+    } else {
+        const u32x4 o = *(const u32x4*)(ctx + off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v += lo_bf(d[r]) * lo_bf(o[r]) + hi_bf(d[r]) * hi_bf(o[r]);
+    }
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    if (sub == 0) {
         const long bb = row / Tp, q = row % Tp;
         delta[(bb * heads + hd) * Tp + q] = v;
     }
@@ -222,10 +253,11 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t*
 // ================================================================================== backward: dK, dV
 // grid (Tp/128, heads, B); wave w owns keys key0 = kt*128 + w*32 .. +31; loops over 32-query tiles.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
-    if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
-    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * 128];   // Q tile, dO tile (32 queries each)
+    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * 128 + 256];   // Q tile, dO tile (32 queries each), lse|delta
     char* sQ = smem;
     char* sD = smem + 32 * 128;
+    float* sL = (float*)(smem + 2 * 32 * 128);                             // [0,32) lse2, [32,64) delta of the tile's queries
+    if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = blockIdx.z, hd = blockIdx.y;
     const int key0 = blockIdx.x * 128 + wave * 32;
@@ -244,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         }
         return;
     }
+    const LaneOffs lo = lane_offs(lane);
     const bf16_t* Kg = a.qkv + (rowbase + key) * a.ld + a.H + hd * HD;
     const bf16_t* Vg = Kg + a.H;
     bf16x8 kf[4], vf[4];
@@ -261,50 +294,72 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const bf16_t* Db = a.dctx + rowbase * a.ldo + hd * HD;
     const float* lse = a.lse2 + ((long)b * a.heads + hd) * a.Tp;
     const float* del = a.delta + ((long)b * a.heads + hd) * a.Tp;
-    u32x4 qreg, dreg;
     const int srow = tid >> 3, sch = tid & 7;          // 256 chunks per tile: one per thread
-    auto load_tile = [&](int t) {
-        qreg = *(const u32x4*)(Qb + (long)(t * 32 + srow) * a.ld + sch * 8);
-        dreg = *(const u32x4*)(Db + (long)(t * 32 + srow) * a.ldo + sch * 8);
-    };
-    load_tile(0);
+    const int soff = tile_off(srow, sch);
+    const long gq = (long)srow * a.ld + sch * 8, gd = (long)srow * a.ldo + sch * 8;
+    u32x4 qreg = *(const u32x4*)(Qb + gq), dreg = *(const u32x4*)(Db + gd);
+    // row statistics ride along with the tile: threads 0..7 carry lse2, 8..15 delta (one float4 each)
+    const float* stat = (tid < 8 ? lse : del) + (tid & 7) * 4;
+    f32x4 sreg = (f32x4)(0.f);
+    if (tid < 16) sreg = *(const f32x4*)stat;
     const bool key_ok = key < len;
+    const bool wave_boundary = key0 + 32 > len;
+    const uint32_t hshift = (key & 1) ? 16u : 0u;
+    const float c = a.c;
+    const uint32_t half = (uint32_t)(a.Tp >> 1);
+    const uint32_t pkey = (uint32_t)((b * a.heads + hd) * a.Tp) * half + (uint32_t)(key >> 1);   // + q*half per element
     for (int t = 0; t < nq; ++t) {
         __syncthreads();
-        *(u32x4*)(sQ + tile_off(srow, sch)) = qreg;
-        *(u32x4*)(sD + tile_off(srow, sch)) = dreg;
+        *(u32x4*)(sQ + soff) = qreg;
+        *(u32x4*)(sD + soff) = dreg;
+        if (tid < 16) *(f32x4*)(sL + tid * 4) = sreg;
         __syncthreads();
-        if (t + 1 < nq) load_tile(t + 1);
+        if (t + 1 < nq) {
+            qreg = *(const u32x4*)(Qb + (long)(t + 1) * 32 * a.ld + gq);
+            dreg = *(const u32x4*)(Db + (long)(t + 1) * 32 * a.ldo + gd);
+            if (tid < 16) sreg = *(const f32x4*)(stat + (t + 1) * 32);
+        }
         // S[q][key] and dP[q][key]
-        f32x16 s = (f32x16)(0.f), dp = (f32x16)(0.f);
+        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sQ, lo, 0, 0), kf[0], (f32x16)(0.f), 0, 0, 0);
+        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sD, lo, 0, 0), vf[0], (f32x16)(0.f), 0, 0, 0);
 #pragma unroll
-        for (int ds = 0; ds < 4; ++ds) {
-            const bf16x8 qa = frag_row(sQ, lane & 31, 2 * ds + h);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ds], s, 0, 0, 0);
-            const bf16x8 da = frag_row(sD, lane & 31, 2 * ds + h);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ds], dp, 0, 0, 0);
+        for (int ds = 1; ds < 4; ++ds) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sQ, lo, 0, ds), kf[ds], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sD, lo, 0, ds), vf[ds], dp, 0, 0, 0);
         }
         float pd[16], dsv[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const int qrow = t * 32 + 8 * g4 + 4 * h;
-            const f32x4 l4 = *(const f32x4*)(lse + qrow);
-            const f32x4 d4 = *(const f32x4*)(del + qrow);
+            const f32x4 l4 = *(const f32x4*)(sL + 8 * g4 + 4 * h);
+            const f32x4 d4 = *(const f32x4*)(sL + 32 + 8 * g4 + 4 * h);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int r = 4 * g4 + rr;
-                float p = key_ok ? exp2f(s[r] * a.c - l4[rr]) : 0.f;
-                float dpe = dp[r];
-                float pdrop = p;
-                if (a.thr16) {
-                    const uint64_t e = ((uint64_t)(b * a.heads + hd) * a.Tp + (uint64_t)(qrow + rr)) * (uint64_t)a.Tp + key;
-                    const bool keep = drop_keep(e, a.seed0, a.seed1, a.thr16);
-                    pdrop = keep ? p * a.dscale : 0.f;
-                    dpe = keep ? dpe * a.dscale : 0.f;
-                }
-                pd[r] = pdrop;
-                dsv[r] = p * (dpe - d4[rr]);
+                pd[4 * g4 + rr] = fast_exp2(fmaf(s[4 * g4 + rr], c, -l4[rr]));
+                dsv[4 * g4 + rr] = d4[rr];
             }
+        }
+        if (wave_boundary) {                                   // wave-uniform: only the wave holding key len-1 masks
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pd[r] = key_ok ? pd[r] : 0.f;
+        }
+        if (a.thr16) {
+            // the pair (keys 2k, 2k+1) of one query shares a hash and sits on lanes l, l^1: the even lane hashes the even
+            // register's query, the odd lane the odd register's, and one DPP quad-permute hands each its partner's value
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t mine = rng_hash(pkey + (uint32_t)(t * 32 + acc_row(r, h) + (lane & 1)) * half, a.seed0, a.seed1);
+                const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);
+                const uint32_t h0 = (lane & 1) ? other : mine, h1 = (lane & 1) ? mine : other;
+                const bool k0 = ((h0 >> hshift) & 0xffffu) >= a.thr16, k1 = ((h1 >> hshift) & 0xffffu) >= a.thr16;
+                const float p0 = pd[r], p1 = pd[r + 1];
+                dsv[r] = p0 * ((k0 ? dp[r] * a.dscale : 0.f) - dsv[r]);
+                dsv[r + 1] = p1 * ((k1 ? dp[r + 1] * a.dscale : 0.f) - dsv[r + 1]);
+                pd[r] = k0 ? p0 * a.dscale : 0.f;
+                pd[r + 1] = k1 ? p1 * a.dscale : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dsv[r] = pd[r] * (dp[r] - dsv[r]);
         }
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
@@ -312,10 +367,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
             const bf16x8 df = pack8(&dsv[8 * sstep]);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 doT = frag_tr(sD, 16 * sstep, dt, lane);
-                dVT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT, pf, dVT[dt], 0, 0, 0);
-                const bf16x8 qT = frag_tr(sQ, 16 * sstep, dt, lane);
-                dKT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, df, dKT[dt], 0, 0, 0);
+                dVT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(sD, lo, sstep, dt), pf, dVT[dt], 0, 0, 0);
+                dKT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(sQ, lo, sstep, dt), df, dKT[dt], 0, 0, 0);
             }
         }
     }
@@ -333,11 +386,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 
 // ================================================================================== backward: dQ
 // grid (Tp/128, heads, B); wave w owns queries q0 = qt*128 + w*32 .. +31; loops over 32-key tiles.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
-    if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 32 * 128];   // K tile, V tile (32 keys each)
     char* sK = smem;
     char* sV = smem + 32 * 128;
+    if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = blockIdx.z, hd = blockIdx.y;
     const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -346,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const long rowbase = (long)b * a.Tp;
     const bf16_t* Qg = a.qkv + (rowbase + q) * a.ld + hd * HD;
     const bf16_t* Dg = a.dctx + (rowbase + q) * a.ldo + hd * HD;
+    const LaneOffs lo = lane_offs(lane);
     bf16x8 qf[4], df[4];
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) {
@@ -359,45 +413,53 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const int nk = (len + 31) >> 5;
     const bf16_t* Kb = a.qkv + rowbase * a.ld + a.H + hd * HD;
     const bf16_t* Vb = Kb + a.H;
-    u32x4 kreg, vreg;
     const int srow = tid >> 3, sch = tid & 7;
-    auto load_tile = [&](int t) {
-        kreg = *(const u32x4*)(Kb + (long)(t * 32 + srow) * a.ld + sch * 8);
-        vreg = *(const u32x4*)(Vb + (long)(t * 32 + srow) * a.ld + sch * 8);
-    };
-    load_tile(0);
-    const uint64_t ebase = ((uint64_t)(b * a.heads + hd) * a.Tp + (uint64_t)q) * (uint64_t)a.Tp;
+    const int soff = tile_off(srow, sch);
+    const long gk = (long)srow * a.ld + sch * 8;
+    u32x4 kreg = *(const u32x4*)(Kb + gk), vreg = *(const u32x4*)(Vb + gk);
+    const uint32_t pbase = (uint32_t)(((b * a.heads + hd) * a.Tp + q) * (a.Tp >> 1));
+    const float c = a.c;
     for (int t = 0; t < nk; ++t) {
         __syncthreads();
-        *(u32x4*)(sK + tile_off(srow, sch)) = kreg;
-        *(u32x4*)(sV + tile_off(srow, sch)) = vreg;
+        *(u32x4*)(sK + soff) = kreg;
+        *(u32x4*)(sV + soff) = vreg;
         __syncthreads();
-        if (t + 1 < nk) load_tile(t + 1);
-        f32x16 sT = (f32x16)(0.f), dpT = (f32x16)(0.f);
+        if (t + 1 < nk) {
+            kreg = *(const u32x4*)(Kb + (long)(t + 1) * 32 * a.ld + gk);
+            vreg = *(const u32x4*)(Vb + (long)(t + 1) * 32 * a.ld + gk);
+        }
+        f32x16 sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sK, lo, 0, 0), qf[0], (f32x16)(0.f), 0, 0, 0);
+        f32x16 dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sV, lo, 0, 0), df[0], (f32x16)(0.f), 0, 0, 0);
 #pragma unroll
-        for (int ds = 0; ds < 4; ++ds) {
-            const bf16x8 ka = frag_row(sK, lane & 31, 2 * ds + h);
-            sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ds], sT, 0, 0, 0);
-            const bf16x8 va = frag_row(sV, lane & 31, 2 * ds + h);
-            dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, df[ds], dpT, 0, 0, 0);
+        for (int ds = 1; ds < 4; ++ds) {
+            sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sK, lo, 0, ds), qf[ds], sT, 0, 0, 0);
+            dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sV, lo, 0, ds), df[ds], dpT, 0, 0, 0);
         }
         float dsv[16];
+        const bool boundary = t * 32 + 32 > len;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = t * 32 + acc_row(r, h);
-            const float p = key < len ? exp2f(sT[r] * a.c - lse_q) : 0.f;
-            float dpe = dpT[r];
-            if (a.thr16) dpe = drop_keep(ebase + key, a.seed0, a.seed1, a.thr16) ? dpe * a.dscale : 0.f;
-            dsv[r] = p * (dpe - del_q);
+            float p = fast_exp2(fmaf(sT[r], c, -lse_q));
+            if (boundary && (t * 32 + acc_row(r, h) >= len)) p = 0.f;
+            dsv[r] = p;
         }
+        if (a.thr16) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int key = t * 32 + acc_row(r, h);
+                const uint32_t hsh = rng_hash(pbase + (uint32_t)(key >> 1), a.seed0, a.seed1);
+                dpT[r] = (hsh & 0xffffu) >= a.thr16 ? dpT[r] * a.dscale : 0.f;
+                dpT[r + 1] = (hsh >> 16) >= a.thr16 ? dpT[r + 1] * a.dscale : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsv[r] *= (dpT[r] - del_q);
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
             const bf16x8 dsf = pack8(&dsv[8 * sstep]);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x8 kT = frag_tr(sK, 16 * sstep, dt, lane);
-                dQT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, dsf, dQT[dt], 0, 0, 0);
-            }
+            for (int dt = 0; dt < 2; ++dt)
+                dQT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(sK, lo, sstep, dt), dsf, dQT[dt], 0, 0, 0);
         }
     }
     bf16_t* dQg = a.dqkv + (rowbase + q) * a.ld + hd * HD;
@@ -453,7 +515,7 @@ extern "C" int aptai_attention_bwd(const void* qkv, const int32_t* lens, const v
     a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.lse2 = (float*)lse2; a.delta = delta_ws; a.dqkv = (bf16_t*)dqkv;
     a.skip_pad_q = dctx_zero_beyond_len;
     const long waves = (long)B * Tp * heads;
-    APTAI_LAUNCH(attn_delta_kernel, dim3((unsigned)ceil_div(waves * 64, 256)), dim3(256), 0, stream,
+    APTAI_LAUNCH(attn_delta_kernel, dim3((unsigned)ceil_div(waves * 8, 256)), dim3(256), 0, stream,
                        (const bf16_t*)dctx, (const bf16_t*)ctx, ctx_f32, delta_ws, (int)B, (int)Tp, (int)H, (int)heads);
     APTAI_CHECK_LAUNCH("attn_delta_kernel");
     dim3 grid((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B);

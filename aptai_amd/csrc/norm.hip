@@ -142,21 +142,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// out[which][col] = sum_b partials[b][which][col].  block = 64 columns x 4 slices of the block list, LDS combine.
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partials, float* __restrict__ out0,
-                                                              float* __restrict__ out1, int nblocks, int cols) {
-    __shared__ float red[4][64];
+// out[which][col] = sum_b partials[b][which][col].  block = 64 columns x 16 slices of the block list (1024 threads),
+// LDS combine: 32 loads per thread for 512 partial blocks.
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ partials, float* __restrict__ out0,
+                                                               float* __restrict__ out1, int nblocks, int cols) {
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;              // index into the concatenated [2][cols] vector
     float s = 0.f;
     if (c < 2 * cols) {
         const int which = c / cols, col = c % cols;
-        for (int b = slice; b < nblocks; b += 4) s += partials[((long)b * 2 + which) * cols + col];
+        for (int b = slice; b < nblocks; b += 16) s += partials[((long)b * 2 + which) * cols + col];
     }
     red[slice][lane] = s;
     __syncthreads();
     if (slice == 0 && c < 2 * cols) {
-        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][lane];
         float* o = (c / cols) ? out1 : out0;
         if (o) o[c % cols] = t;
     }
@@ -216,7 +219,7 @@ extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* m
     APTAI_CHECK_LAUNCH("ln_bwd_kernel");
     if (dgamma || dbeta) {
         const int n = 2 * (int)cols;
-        APTAI_LAUNCH(colsum_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, stream,
+        APTAI_LAUNCH(colsum_partials_kernel, dim3((n + 63) / 64), dim3(1024), 0, stream,
                            (const float*)workspace, dgamma, dbeta, (int)blocks, (int)cols);
         APTAI_CHECK_LAUNCH("colsum_partials_kernel");
     }

@@ -104,7 +104,10 @@ def _seed(base: int, *ids: int) -> int:
     s = base & 0xFFFFFFFFFFFF
     for i in ids:
         s = (s * 1000003 + i + 1) & 0xFFFFFFFFFFFFFFFF
-    return s
+    # splitmix64 finaliser: the kernels use the two 32-bit halves as independent stream keys (csrc/common.h rng_hash)
+    s = ((s ^ (s >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    s = ((s ^ (s >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return s ^ (s >> 31)
 
 
 # =================================================================================== encoder layer
