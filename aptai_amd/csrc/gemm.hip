@@ -96,26 +96,26 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row_base, 
     }
 }
 
+// XCD-aware bijective remap: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// one 128 x 128 output tile: `bid` is the (already remapped) tile index of problem g, `batch` < 0 = not batched
 template <bool A_KM, bool B_KM, bool OUT_F32>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const int batch, const int split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware bijective remap: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
-    const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
     const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    if (gridDim.y > 1) {
-        const int bo = blockIdx.y / g.nb_inner, bi = blockIdx.y % g.nb_inner;
+    if (batch >= 0) {
+        const int bo = batch / g.nb_inner, bi = batch % g.nb_inner;
         g.A += bo * g.sA[0] + bi * g.sA[1];
         g.B += bo * g.sB[0] + bi * g.sB[1];
         const long co = bo * g.sC[0] + bi * g.sC[1];
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
         if (g.residual) g.residual += bo * g.sR[0] + bi * g.sR[1];
         if (g.aux) g.aux += bo * g.sAux[0] + bi * g.sAux[1];
     }
-    const int split = blockIdx.z;
     const int total_kt = g.K / BK;
     const int kt_begin = split * g.ktiles_per_split;
     int kt_end = kt_begin + g.ktiles_per_split;
@@ -265,6 +264,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
         *(u32x4*)((bf16_t*)g.C + (long)m * g.ldc + n) =
             (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
     }
+}
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
+    gemm_tile_body<A_KM, B_KM, OUT_F32>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), gridDim.y > 1 ? (int)blockIdx.y : -1,
+                                        blockIdx.z);
+}
+
+// Grouped launch: the tiles of up to MAX_GROUP independent problems of one operand layout in ONE grid.  Made for the four
+// weight gradients of a transformer layer (dW = dY^T X, K = B*Tp = 8192 rows each): separately each is 36..144 tiles and
+// needs split-K slabs plus a reduce launch to fill 256 CUs; together they are 432 full-K tiles = one round of the 512
+// block slots, with no slabs, no reduce kernels and a 128-K-tile main loop per block.
+constexpr int MAX_GROUP = 8;
+struct GroupArgs {
+    GemmArgs p[MAX_GROUP];
+    int tile_end[MAX_GROUP];        // running sum of tiles_m * tiles_n
+    int n, total;
+};
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_grouped_kernel(GroupArgs ga) {
+    const int bid = xcd_remap(blockIdx.x, ga.total);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i)
+        if (i < ga.n && bid >= ga.tile_end[i - 1]) pi = i;
+    const int first = pi ? ga.tile_end[pi - 1] : 0;
+    gemm_tile_body<A_KM, B_KM, OUT_F32>(ga.p[pi], bid - first, -1, 0);
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]
@@ -571,10 +598,295 @@ int launch_gemm256(GemmArgs g, int nbatch, int nsplit, hipStream_t stream) {
     return APTAI_OK;
 }
 
+
+// =====================================================================================================================
+// 128 x 192 x 64 tile, 512 threads = 8 waves (2 M-rows x 4 N-columns, wave tile 64 x 48 = 4 x 3 MFMA tiles), ONE block
+// per CU, 3-stage LDS ring (120 KiB).
+//
+// Why this shape: the transformer GEMMs of the hot path are [B*Tp = 8192] x {768, 2304, 3072}.  With 128 x 192 tiles
+// that is 64 x {4, 12, 16} = 256 / 768 / 1024 tiles = exactly 1 / 3 / 4 rounds of the 256 CUs, where the 128 x 128 kernel
+// (2 blocks per CU, 512 slots) runs 0.75 / 2.25 / 3 rounds and the 256 x 256 kernel 0.375 / 1.125 / 1.5.
+//
+// Pipeline: K-tile kt lives in ring slot kt % 3 and is staged two K-tiles ahead by LDS-DMA; every thread issues exactly
+// 5 x 16 B per stage in every operand layout, so `s_waitcnt vmcnt(5)` retires "all but the newest stage".  One barrier
+// per K-tile, placed BETWEEN the two k-halves: the fragments of (kt+1, half 0) are read while the MFMAs of (kt, half 1)
+// run, and those of (kt+1, half 1) under the MFMAs of (kt+1, half 0), so no LDS latency sits on the MFMA chain.
+//   RAW: a thread waits for its own stage-(kt+1) loads, then crosses the barrier every wave crosses, before anyone reads
+//        slot (kt+1) % 3.   WAR: slot kt % 3 is restaged (stage kt+3) after that same barrier, which each wave enters
+//        with lgkmcnt(0), i.e. with all its reads of slot kt % 3 complete.
+// K-major operands are stored as 64-row panels [64 k][128 B] (5 = 2 + 3 panels per stage) with the 32-byte-granular
+// swizzle pn_swz: the 8 k-rows one ds_read_b64_tr_b16 lane group touches land in 8 distinct 32-B bank slots.
+constexpr int T3_THREADS = 512;
+constexpr int T3_BM = 128, T3_BN = 192;
+constexpr int T3_A_BYTES = T3_BM * BK * 2;              // 16 KiB
+constexpr int T3_B_BYTES = T3_BN * BK * 2;              // 24 KiB
+constexpr int T3_STAGE = T3_A_BYTES + T3_B_BYTES;       // 40 KiB
+constexpr int T3_SMEM = 3 * T3_STAGE;                   // 120 KiB
+constexpr int T3_EPI_PITCH = T3_BN * 4 + 16;            // 784 B: 196 dwords = 4 mod 32 -> conflict-free 16-B row writes
+static_assert(T3_BM * T3_EPI_PITCH <= T3_SMEM, "epilogue tile must fit the staging LDS");
+
+__device__ __forceinline__ int pn_swz(int krow) { return (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1; }
+
+// per-thread source pointer of staging instruction `it` of an operand tile at K offset 0
+template <bool KM>
+__device__ __forceinline__ const bf16_t* stage3_src(const bf16_t* __restrict__ base, long ld, int row0, int rows_total, int it,
+                                                    int tid) {
+    if (!KM) {
+        const int slot = it * T3_THREADS + tid, row = slot >> 3, pc = slot & 7;
+        int grow = row0 + row;
+        grow = grow < rows_total ? grow : rows_total - 1;
+        return base + (long)grow * ld + ((pc ^ (row & 7)) << 3);
+    } else {
+        const int krow = tid >> 3, pc = tid & 7;
+        int col = row0 + it * 64 + ((pc ^ pn_swz(krow)) << 3);
+        col = col <= rows_total - 8 ? col : rows_total - 8;
+        return base + (long)krow * ld + col;
+    }
+}
+
+template <bool KM>
+__device__ __forceinline__ bf16x8 read_frag3(const char* lds_tile, int row_base, int ks, int lane) {
+    if (!KM) {
+        return read_frag<false>(lds_tile, row_base, ks, lane);
+    } else {
+        const char* panel = lds_tile + (row_base >> 6) * 8192;
+        const int rb = row_base & 63;
+        const int gq = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3;
+        const int ch = (rb >> 3) + (p >> 1);
+        const int sub = (p & 1) << 3;
+        const int k_lo = ks * 32 + gq * 8 + qq;
+        const int k_hi = k_lo + 4;
+        const char* a0 = panel + k_lo * 128 + ((ch ^ pn_swz(k_lo)) << 4) + sub;
+        const char* a1 = panel + k_hi * 128 + ((ch ^ pn_swz(k_hi)) << 4) + sub;
+        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)a0);
+        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)a1);
+        short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, r);
+    }
+}
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+__global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wave_base_tid = wave * 64;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+    const int m0 = tile_m * T3_BM, n0 = tile_n * T3_BN;
+    if (gridDim.y > 1) {
+        const int bo = blockIdx.y / g.nb_inner, bi = blockIdx.y % g.nb_inner;
+        g.A += bo * g.sA[0] + bi * g.sA[1];
+        g.B += bo * g.sB[0] + bi * g.sB[1];
+        const long co = bo * g.sC[0] + bi * g.sC[1];
+        g.C = OUT_F32 ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
+        if (g.out_pre) g.out_pre += co;
+        if (g.bias) g.bias += bo * g.sBias[0] + bi * g.sBias[1];
+        if (g.residual) g.residual += bo * g.sR[0] + bi * g.sR[1];
+        if (g.aux) g.aux += bo * g.sAux[0] + bi * g.sAux[1];
+    }
+    const int split = blockIdx.z;
+    const int total_kt = g.K / BK;
+    const int kt_begin = split * g.ktiles_per_split;
+    int kt_end = kt_begin + g.ktiles_per_split;
+    kt_end = kt_end < total_kt ? kt_end : total_kt;
+    const int nk = kt_end - kt_begin;
+
+    // staging sources advance by one K-tile per stage() call (stages are issued in K order)
+    const bf16_t* pa[2];
+    const bf16_t* pb[3];
+    const long stepA = A_KM ? (long)BK * g.lda : (long)BK;
+    const long stepB = B_KM ? (long)BK * g.ldb : (long)BK;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) pa[it] = stage3_src<A_KM>(g.A, g.lda, m0, g.M, it, tid) + (long)kt_begin * stepA;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) pb[it] = stage3_src<B_KM>(g.B, g.ldb, n0, g.N, it, tid) + (long)kt_begin * stepB;
+    auto stage = [&](int slot) {
+        char* buf = smem + slot * T3_STAGE + wave_base_tid * 16;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pa[it]), LDS_PTR(buf + it * (T3_THREADS * 16)), 16, 0, 0);
+            pa[it] += stepA;
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pb[it]), LDS_PTR(buf + T3_A_BYTES + it * (T3_THREADS * 16)), 16, 0, 0);
+            pb[it] += stepB;
+        }
+    };
+
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 af[2][4], bfr[2][3];
+    auto read_half = [&](int slot, int ks) {
+        const char* sa = smem + slot * T3_STAGE;
+        const char* sb = sa + T3_A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[ks][i] = read_frag3<A_KM>(sa, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bfr[ks][j] = read_frag3<B_KM>(sb, wn * 48 + j * 16, ks, lane);
+    };
+    auto mfma_half = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+    };
+
+    if (nk > 0) {
+        stage(0);
+        if (nk > 1) stage(1);
+        if (nk > 2) stage(2);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_half(0, 0);
+        read_half(0, 1);
+    }
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nxt = cur == 2 ? 0 : cur + 1;
+        mfma_half(0);
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 3 < nk) stage(cur);
+            read_half(nxt, 0);
+        }
+        mfma_half(1);
+        if (kt + 1 < nk) read_half(nxt, 1);
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ------------------------------------------------------------------ epilogue (same scheme as gemm_kernel)
+    // 128 x 192 outputs = 3072 chunks of 8 columns = 6 passes x 512 threads; chunk c -> row c / 24, column 8 * (c % 24)
+    const int flags = g.flags;
+    u32x4 resv[6], auxv[6];
+#pragma unroll
+    for (int pass = 0; pass < 6; ++pass) {
+        resv[pass] = (u32x4){0u, 0u, 0u, 0u};
+        auxv[pass] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    if (!OUT_F32 && (flags & (APTAI_EPI_RESIDUAL | APTAI_EPI_DGELU))) {     // uniform; addresses clamped, no per-lane branches
+#pragma unroll
+        for (int pass = 0; pass < 6; ++pass) {
+            const int c = pass * T3_THREADS + tid, ml = c / 24, cl = (c - ml * 24) * 8;
+            int m = m0 + ml, n = n0 + cl;
+            m = m < g.M ? m : g.M - 1;
+            n = n <= g.N - 8 ? n : g.N - 8;
+            if (flags & APTAI_EPI_RESIDUAL) resv[pass] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+            if (flags & APTAI_EPI_DGELU) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ml = wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int nl = wn * 48 + j * 16 + (lane >> 4) * 4;
+            *(f32x4*)(smem + ml * T3_EPI_PITCH + nl * 4) = acc[i][j];
+        }
+    }
+    __syncthreads();
+    const float alpha = (flags & APTAI_EPI_ALPHA) ? g.alpha : 1.0f;
+    uint32_t sd0 = g.seed0, sd1 = g.seed1;
+    if (flags & APTAI_EPI_DROPOUT) apply_salt(g.salt, sd0, sd1);
+#pragma unroll
+    for (int pass = 0; pass < 6; ++pass) {
+        const int c = pass * T3_THREADS + tid, ml = c / 24, cl = (c - ml * 24) * 8;
+        const int m = m0 + ml, n = n0 + cl;
+        if (m >= g.M || n >= g.N) continue;
+        const f32x4 v0 = *(const f32x4*)(smem + ml * T3_EPI_PITCH + cl * 4);
+        const f32x4 v1 = *(const f32x4*)(smem + ml * T3_EPI_PITCH + cl * 4 + 16);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (flags & APTAI_EPI_BIAS) {
+            const f32x4 b0 = *(const f32x4*)(g.bias + n), b1 = *(const f32x4*)(g.bias + n + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = fmaf(v[r], alpha, b0[r]); v[4 + r] = fmaf(v[4 + r], alpha, b1[r]); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] *= alpha;
+        }
+        if (OUT_F32) {
+            float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
+            *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            continue;
+        }
+        if (g.out_pre)
+            *(u32x4*)(g.out_pre + (long)m * g.ldc + n) =
+                (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        if (flags & APTAI_EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
+        }
+        if (flags & APTAI_EPI_DROPOUT) {
+            const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                const uint32_t hsh = drop_hash_pair(e + r, sd0, sd1);
+                v[r] = (hsh & 0xffffu) >= g.thr16 ? v[r] * g.dscale : 0.f;
+                v[r + 1] = (hsh >> 16) >= g.thr16 ? v[r + 1] * g.dscale : 0.f;
+            }
+        }
+        if (flags & APTAI_EPI_DGELU) {
+            const u32x4 a = auxv[pass];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[2 * r] *= gelu_fast_grad(lo_bf(a[r]));
+                v[2 * r + 1] *= gelu_fast_grad(hi_bf(a[r]));
+            }
+        }
+        if (flags & APTAI_EPI_RESIDUAL) {
+            const u32x4 a = resv[pass];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[2 * r] += lo_bf(a[r]); v[2 * r + 1] += hi_bf(a[r]); }
+        }
+        *(u32x4*)((bf16_t*)g.C + (long)m * g.ldc + n) =
+            (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        __builtin_amdgcn_sched_barrier(0);             // keep the passes apart: interleaving all six spills
+    }
+}
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+int launch_gemm192(GemmArgs g, int nbatch, int nsplit, hipStream_t stream) {
+    auto kern = gemm192_kernel<A_KM, B_KM, OUT_F32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T3_SMEM);
+        attr_set = true;
+    }
+    g.tiles_m = (int)ceil_div(g.M, T3_BM);
+    g.tiles_n = (int)ceil_div(g.N, T3_BN);
+    dim3 grid(g.tiles_m * g.tiles_n, nbatch, nsplit);
+    APTAI_LAUNCH(kern, grid, dim3(T3_THREADS), T3_SMEM, stream, g);
+    APTAI_CHECK_LAUNCH("gemm192_kernel");
+    return APTAI_OK;
+}
+
 }  // namespace
 
-extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// validates one descriptor and fills the kernel arguments (tiles for the 128-tile kernel; the others recompute them)
+static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& nsplit) {
     APTAI_REQUIRE(d != nullptr, "aptai_gemm_bf16: null descriptor");
     APTAI_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "aptai_gemm_bf16: empty problem M=%ld N=%ld K=%ld", (long)d->M,
                   (long)d->N, (long)d->K);
@@ -593,7 +905,6 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     if (d->flags & APTAI_EPI_RESIDUAL) APTAI_REQUIRE(d->residual != nullptr, "aptai_gemm_bf16: EPI_RESIDUAL without residual");
     if (d->flags & APTAI_EPI_DGELU) APTAI_REQUIRE(d->aux != nullptr, "aptai_gemm_bf16: EPI_DGELU without aux");
 
-    GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)d->A; g.lda = d->lda;
     g.B = (const bf16_t*)d->B; g.ldb = d->ldb;
@@ -613,12 +924,12 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     g.tiles_m = (int)ceil_div(d->M, BM);
     g.tiles_n = (int)ceil_div(d->N, BN);
     const int total_kt = g.K / BK;
-    int nsplit = d->split_k > 0 ? d->split_k : 1;
+    nsplit = d->split_k > 0 ? d->split_k : 1;
     if (nsplit > total_kt) nsplit = total_kt;
     g.ktiles_per_split = (int)ceil_div(total_kt, nsplit);
     nsplit = (int)ceil_div(total_kt, g.ktiles_per_split);
 
-    int nbatch = 1;
+    nbatch = 1;
     g.nb_inner = 1;
     if (d->batch_outer > 1 || d->batch_inner > 1) {
         const int bo = d->batch_outer > 0 ? d->batch_outer : 1, bi = d->batch_inner > 0 ? d->batch_inner : 1;
@@ -636,7 +947,6 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     const bool f32 = d->out_f32 != 0;
     if (nbatch > 1) APTAI_REQUIRE(!(f32 && (d->split_k > 1 || d->accumulate)), "aptai_gemm_bf16: batched GEMM cannot split-K/accumulate");
     if (!f32) APTAI_REQUIRE(nsplit == 1, "aptai_gemm_bf16: split-K needs fp32 output");
-    float* final_out = (float*)d->C;
     if (f32 && (nsplit > 1 || d->accumulate)) {
         APTAI_REQUIRE(d->workspace != nullptr, "aptai_gemm_bf16: split-K / accumulate needs a workspace");
         APTAI_REQUIRE(d->ldc == d->N, "aptai_gemm_bf16: split-K output must be dense (ldc == N)");
@@ -644,6 +954,17 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         g.C = d->workspace;
         g.slab_stride = (long)d->M * d->N;
     }
+    return APTAI_OK;
+}
+
+extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GemmArgs g;
+    int nbatch = 1, nsplit = 1;
+    const int brc = build_args(d, g, nbatch, nsplit);
+    if (brc != APTAI_OK) return brc;
+    const bool f32 = d->out_f32 != 0;
+    float* final_out = (float*)d->C;
     // tile selection: the 256x256 deep-pipelined kernel when the grid still fills the chip, else 128x128 (2 blocks/CU)
     int tile = d->tile;
     if (tile == 0) {
@@ -665,6 +986,12 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         tile = (d->M >= 256 && d->N >= 256 && 1.25 * e256 > e128) ? 256 : 128;
     }
     int rc;
+    if (tile == 192) {
+        if (!d->a_kmajor && !d->b_kmajor) rc = f32 ? launch_gemm192<false, false, true>(g, nbatch, nsplit, stream) : launch_gemm192<false, false, false>(g, nbatch, nsplit, stream);
+        else if (!d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm192<false, true, true>(g, nbatch, nsplit, stream) : launch_gemm192<false, true, false>(g, nbatch, nsplit, stream);
+        else if (d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm192<true, true, true>(g, nbatch, nsplit, stream) : launch_gemm192<true, true, false>(g, nbatch, nsplit, stream);
+        else APTAI_FAIL(APTAI_ERR_INVALID, "aptai_gemm_bf16: A K-major with B K-contiguous is not built");
+    } else
     if (tile == 256) {
         if (!d->a_kmajor && !d->b_kmajor) rc = f32 ? launch_gemm256<false, false, true>(g, nbatch, nsplit, stream) : launch_gemm256<false, false, false>(g, nbatch, nsplit, stream);
         else if (!d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm256<false, true, true>(g, nbatch, nsplit, stream) : launch_gemm256<false, true, false>(g, nbatch, nsplit, stream);
@@ -683,6 +1010,45 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
                            n4, g.slab_stride / 4, nsplit, d->accumulate ? 1 : 0);
         APTAI_CHECK_LAUNCH("splitk_reduce_kernel");
     }
+    return APTAI_OK;
+}
+
+extern "C" int aptai_gemm_bf16_grouped(const aptai_gemm_desc* descs, int n, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APTAI_REQUIRE(descs != nullptr && n >= 1 && n <= MAX_GROUP, "aptai_gemm_bf16_grouped: need 1..%d problems, got %d", MAX_GROUP, n);
+    GroupArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const aptai_gemm_desc* d = descs + i;
+        int nbatch = 1, nsplit = 1;
+        const int brc = build_args(d, ga.p[i], nbatch, nsplit);
+        if (brc != APTAI_OK) return brc;
+        APTAI_REQUIRE(nbatch == 1 && nsplit == 1 && !d->accumulate, "aptai_gemm_bf16_grouped: problem %d: no batching, split-K or accumulate", i);
+        APTAI_REQUIRE(d->a_kmajor == descs[0].a_kmajor && d->b_kmajor == descs[0].b_kmajor && (d->out_f32 != 0) == (descs[0].out_f32 != 0),
+                      "aptai_gemm_bf16_grouped: problem %d: all problems must share the operand layout and output type", i);
+        total += ga.p[i].tiles_m * ga.p[i].tiles_n;
+        ga.tile_end[i] = total;
+    }
+    ga.n = n;
+    ga.total = total;
+    const bool f32 = descs[0].out_f32 != 0, akm = descs[0].a_kmajor != 0, bkm = descs[0].b_kmajor != 0;
+    APTAI_REQUIRE(!(akm && !bkm), "aptai_gemm_bf16_grouped: A K-major with B K-contiguous is not built");
+#define APTAI_GROUPED(AK, BK_, F)                                                                                      \
+    do {                                                                                                              \
+        auto kern = gemm_grouped_kernel<AK, BK_, F>;                                                                  \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);     \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        APTAI_LAUNCH(kern, dim3(total), dim3(NTHREADS), SMEM_BYTES, stream, ga);                                      \
+    } while (0)
+    if (!akm && !bkm) { if (f32) APTAI_GROUPED(false, false, true); else APTAI_GROUPED(false, false, false); }
+    else if (!akm && bkm) { if (f32) APTAI_GROUPED(false, true, true); else APTAI_GROUPED(false, true, false); }
+    else { if (f32) APTAI_GROUPED(true, true, true); else APTAI_GROUPED(true, true, false); }
+#undef APTAI_GROUPED
+    APTAI_CHECK_LAUNCH("gemm_grouped_kernel");
     return APTAI_OK;
 }
 

@@ -67,16 +67,15 @@ def _dev(*ts) -> None:
             raise _lib.AptaiHipError("aptai_amd ops need tensors on the MI355X (no CPU fallback)")
 
 
-def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, ldb=None, out=None, ldc=None,
-         a_kmajor=False, b_kmajor=False, out_f32=False, bias=None, gelu=False, residual=None, out_pre=None,
-         dgelu_aux=None, alpha: Optional[float] = None, dropout_p: float = 0.0, seed: int = 0, split_k: int = 1,
-         accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None, tile: int = 0,
-         ldaux=None) -> torch.Tensor:
-    """C[M,N] = rowop(A)[M,K] . colop(B)[N,K]^T.  See aptai_gemm_bf16 in include/aptai_hip.h."""
+def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, ldb=None, out=None, ldc=None,
+               a_kmajor=False, b_kmajor=False, out_f32=False, bias=None, gelu=False, residual=None, out_pre=None,
+               dgelu_aux=None, alpha: Optional[float] = None, dropout_p: float = 0.0, seed: int = 0, split_k: int = 1,
+               accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None, tile: int = 0,
+               ldaux=None):
+    """Fills one aptai_gemm_desc in place; returns (out, workspace) - the caller keeps them alive across the launch."""
     _dev(a, b, out, bias, residual, out_pre, dgelu_aux)
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
-    d = GemmDesc()
     d.A, d.lda = a.data_ptr(), lda if lda is not None else (a.stride(0))
     d.B, d.ldb = b.data_ptr(), ldb if ldb is not None else (b.stride(0))
     d.C, d.ldc = out.data_ptr(), ldc if ldc is not None else out.stride(0)
@@ -121,17 +120,63 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, *, lda=None, 
         if workspace is None or workspace.numel() * workspace.element_size() < need:
             workspace = torch.empty(need, device=a.device, dtype=torch.uint8)
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    return out, workspace
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, **kw) -> torch.Tensor:
+    """C[M,N] = rowop(A)[M,K] . colop(B)[N,K]^T.  See aptai_gemm_bf16 in include/aptai_hip.h (keywords: _gemm_desc)."""
+    d = GemmDesc()
+    out, _ws_keep = _gemm_desc(d, a, b, M, N, K, **kw)
     pr = _probe
-    if pr is not None and pr.key == (bool(a_kmajor), bool(b_kmajor), bool(out_f32)):
+    if pr is not None and pr.key == (bool(d.a_kmajor), bool(d.b_kmajor), bool(d.out_f32)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _lib.check(_lib.lib().aptai_gemm_bf16(ctypes.byref(d), c_void_p(_stream())), "aptai_gemm_bf16")
         e1.record()
+        batch = kw.get("batch")
         nb = (batch.get("outer", 1) * batch.get("inner", 1)) if batch else 1
         pr.records.append((2.0 * M * N * K * nb, e0, e1))
         return out
     _lib.check(_lib.lib().aptai_gemm_bf16(ctypes.byref(d), c_void_p(_stream())), "aptai_gemm_bf16")
     return out
+
+
+def gemm_grouped(problems) -> list:
+    """One launch for up to 8 independent GEMMs of one operand layout (aptai_gemm_bf16_grouped).
+    problems: iterable of (a, b, M, N, K, kwargs-dict) with the keywords of gemm(); returns the outputs in order."""
+    problems = list(problems)
+    descs = (GemmDesc * len(problems))()
+    outs, keep = [], []
+    flops = 0.0
+    for d, (a, b, M, N, K, kw) in zip(descs, problems):
+        out, ws = _gemm_desc(d, a, b, M, N, K, **kw)
+        outs.append(out)
+        keep.append(ws)
+        flops += 2.0 * M * N * K
+    pr = _probe
+    d0 = descs[0]
+    if pr is not None and pr.key == (bool(d0.a_kmajor), bool(d0.b_kmajor), bool(d0.out_f32)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.lib().aptai_gemm_bf16_grouped(descs, len(problems), c_void_p(_stream())), "aptai_gemm_bf16_grouped")
+        e1.record()
+        pr.records.append((flops, e0, e1))
+        return outs
+    _lib.check(_lib.lib().aptai_gemm_bf16_grouped(descs, len(problems), c_void_p(_stream())), "aptai_gemm_bf16_grouped")
+    return outs
+
+
+_ONES = {}
+
+
+def ones_kmajor(K: int, device) -> torch.Tensor:
+    """[K][8] bf16 ones: the A operand that turns a column sum into a grouped-GEMM problem (bias gradients)."""
+    key = (K, str(device))
+    t = _ONES.get(key)
+    if t is None:
+        t = torch.ones((K, 8), device=device, dtype=torch.bfloat16)
+        _ONES[key] = t
+    return t
 
 
 # ----------------------------------------------------------------------------- LayerNorm

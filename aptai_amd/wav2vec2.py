@@ -187,11 +187,14 @@ class _LayerImpl:
             if d_ffn_out is None:
                 d_ffn_out = ds2
             ffn_in = s.x1
-        dw2, dbias2 = on_side(lambda: (ops.gemm(d_ffn_out, s.hact, H, I, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[3]),
-                                       ops.colsum(d_ffn_out, M, H)))
+        grouped = _GROUPED_WGRAD
+        if not grouped:
+            dw2, dbias2 = on_side(lambda: (ops.gemm(d_ffn_out, s.hact, H, I, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[3]),
+                                           ops.colsum(d_ffn_out, M, H)))
         du = ops.gemm(d_ffn_out, w.w2, M, I, H, b_kmajor=True, dgelu_aux=s.u, dropout_p=p_a, seed=_seed(self.seed, 3))
-        dw1, dbias1 = on_side(lambda: (ops.gemm(du, ffn_in, I, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[2]),
-                                       ops.colsum(du, M, I)))
+        if not grouped:
+            dw1, dbias1 = on_side(lambda: (ops.gemm(du, ffn_in, I, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[2]),
+                                           ops.colsum(du, M, I)))
         if pre:
             dn2 = ops.gemm(du, w.w1, M, H, I, b_kmajor=True)
             ds1, d_att_out, dg2, db2 = ops.layernorm_bwd(dn2, s.s1, s.m2, s.r2, ln2w, dres=ds2, dropout_p=p_h,
@@ -202,25 +205,39 @@ class _LayerImpl:
         if d_att_out is None:
             d_att_out = ds1
         # ---- attention block
-        dwo, dbo = on_side(lambda: (ops.gemm(d_att_out, s.ctx, H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[1]),
-                                    ops.colsum(d_att_out, M, H)))
+        if not grouped:
+            dwo, dbo = on_side(lambda: (ops.gemm(d_att_out, s.ctx, H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[1]),
+                                        ops.colsum(d_att_out, M, H)))
         dctx = ops.gemm(d_att_out, w.wo, M, H, H, b_kmajor=True)
         dqkv = ops.attention_bwd(s.qkv, self.lens, s.ctx, dctx, s.lse, g.B, g.Tp, H, heads, dropout_p=p_att,
                                  seed=_seed(self.seed, 1), dctx_zero_beyond_len=True)
         attn_in = s.n1 if pre else s.x
-        dwqkv, dbqkv = on_side(lambda: (ops.gemm(dqkv, attn_in, 3 * H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[0]),
-                                        ops.colsum(dqkv, M, 3 * H)))
+        if not grouped:
+            dwqkv, dbqkv = on_side(lambda: (ops.gemm(dqkv, attn_in, 3 * H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[0]),
+                                            ops.colsum(dqkv, M, 3 * H)))
         if pre:
             dn1 = ops.gemm(dqkv, w.wqkv, M, H, 3 * H, b_kmajor=True)
             dx, _, dg1, db1 = ops.layernorm_bwd(dn1, s.x, s.m1, s.r1, ln1w, dres=ds1)
         else:
             dx = ops.gemm(dqkv, w.wqkv, M, H, 3 * H, b_kmajor=True, residual=ds1)
+        if grouped:
+            # all weight and bias gradients of the layer in ONE launch (aptai_gemm_bf16_grouped): 4 x (dY^T X) + 4 x (1^T dY),
+            # 432 + 54 full-K tiles for wav2vec2-base = one round of the 512 block slots, no split-K slabs, no reduce kernels
+            tn = dict(a_kmajor=True, b_kmajor=True, out_f32=True)
+            ones = ops.ones_kmajor(M, dy.device)
+            dw2, dw1, dwo, dwqkv, r2, r1, ro, rq = ops.gemm_grouped([
+                (d_ffn_out, s.hact, H, I, M, tn), (du, ffn_in, I, H, M, tn), (d_att_out, s.ctx, H, H, M, tn),
+                (dqkv, attn_in, 3 * H, H, M, tn),
+                (ones, d_ffn_out, 8, H, M, tn), (ones, du, 8, I, M, tn), (ones, d_att_out, 8, H, M, tn),
+                (ones, dqkv, 8, 3 * H, M, tn)])
+            dbias2, dbias1, dbo, dbqkv = r2[0], r1[0], ro[0], rq[0]
         main.wait_stream(side)
         return dx, (dg1, db1, dg2, db2, dwqkv[0:H], dwqkv[H:2 * H], dwqkv[2 * H:3 * H], dbqkv[0:H], dbqkv[H:2 * H],
                     dbqkv[2 * H:3 * H], dwo, dbo, dw1, dbias1, dw2, dbias2)
 
 
 _SIDE_STREAMS = {}
+_GROUPED_WGRAD = os.environ.get("APTAI_GROUPED_WGRAD", "1") != "0"
 _USE_SIDE_STREAM = os.environ.get("APTAI_SIDE_STREAM", "0") != "0"     # measured neutral on MI355X (A/B 15.95 vs 15.98 ms/step)
 
 

@@ -71,10 +71,17 @@ typedef struct {
     int batch_outer, batch_inner;
     int64_t batch_stride_a[2], batch_stride_b[2], batch_stride_c[2], batch_stride_bias[2], batch_stride_res[2],
         batch_stride_aux[2];
-    int tile;                       /* 0 = auto, 128 = 128x128 tile kernel, 256 = 256x256 deep-pipelined kernel */
+    int tile;                       /* 0 = auto, 128 = 128x128 tile kernel (2 blocks/CU), 192 = 128x192 tile, 3-stage ring
+                                       (1 block/CU), 256 = 256x256 deep-pipelined kernel */
 } aptai_gemm_desc;
 
 int aptai_gemm_bf16(const aptai_gemm_desc* desc, void* stream);
+/* n (<= 8) independent problems of ONE operand layout / output type in a single launch (no batching, split-K or
+ * accumulate).  Made for the per-layer weight and bias gradients of the encoder backward, which autograd computes as
+ * separate `grad_out.t() @ input` / `grad_out.sum(0)` kernels behind HF:478-480,575-654 (nn.Linear backward): together
+ * their full-K tiles fill the 256 CUs once, where each alone needs split-K slabs and a reduce pass.  A bias gradient is
+ * the problem M = 8, A = ones[K][8] (K-major), row 0 of the [8][N] fp32 result. */
+int aptai_gemm_bf16_grouped(const aptai_gemm_desc* descs, int n, void* stream);
 int64_t aptai_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
 
 /* ------------------------------------------------------------------------------------------------ LayerNorm

@@ -46,7 +46,9 @@ def _worker(rank, world, port, comm_bf16, q):
         loss = ((out - mine["y"]) ** 2).sum() / (batch["x"].shape[0] * 4) * world
         loss.backward()
         red.finish()
-    q.put((rank, {n: p.grad.numpy().copy() for n, p in model.named_parameters()}))      # by value: the sender may exit first
+    # by value (the sender may exit first); a parameter no rank touched keeps grad None, like the single-process run
+    q.put((rank, {n: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy() for n, p in model.named_parameters()}))
+    assert model[2].weight.grad is None
     dist.destroy_process_group()
 
 

@@ -25,10 +25,24 @@ def _cmp(got, ref, tol=1e-2):
     assert err <= tol * scale, f"max err {err} vs scale {scale}"
 
 
-@pytest.fixture(scope="module")
-def ops():
+class _TileOps:
+    """aptai_amd.ops with the GEMM tile forced (0 = the dispatcher's own choice)."""
+
+    def __init__(self, ops, tile):
+        self._ops, self._tile = ops, tile
+
+    def __getattr__(self, k):
+        return getattr(self._ops, k)
+
+    def gemm(self, *a, **kw):
+        kw.setdefault("tile", self._tile)
+        return self._ops.gemm(*a, **kw)
+
+
+@pytest.fixture(scope="module", params=[0, 128, 192], ids=["auto", "t128", "t192"])
+def ops(request):
     from aptai_amd import ops
-    return ops
+    return _TileOps(ops, request.param)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 768, 512), (1000, 768, 768), (499, 2304, 768),
@@ -145,6 +159,37 @@ def test_tn_strided_operand(ops):
     out = ops.gemm(dy.cuda(), x.cuda(), 256, 3 * C, T, a_kmajor=True, b_kmajor=True, out_f32=True, ldb=2 * C)
     A = torch.stack([x[2 * t:2 * t + 3].reshape(-1) for t in range(T)]).float()
     _cmp(out, dy.float().t() @ A, tol=1e-3)
+
+
+def test_grouped_wgrad_and_bias_grads_match_separate_launches():
+    """aptai_gemm_bf16_grouped: weight gradients dY^T X of different shapes plus column sums as (ones^T dY) problems in one
+    launch; must equal the separate launches bit for bit (same tiles, same K order) and fp32 torch within bf16-input noise."""
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(11)
+    K = 1024
+    dy1, x1 = _rand((K, 768), g).cuda(), _rand((K, 256), g).cuda()
+    dy2, x2 = _rand((K, 136), g).cuda(), _rand((K, 768), g).cuda()
+    dy3, x3 = _rand((K, 2304), g).cuda(), _rand((K, 128), g).cuda()
+    tn = dict(a_kmajor=True, b_kmajor=True, out_f32=True)
+    ones = ops.ones_kmajor(K, dy1.device)
+    outs = ops.gemm_grouped([(dy1, x1, 768, 256, K, tn), (dy2, x2, 136, 768, K, tn), (dy3, x3, 2304, 128, K, tn),
+                             (ones, dy1, 8, 768, K, tn), (ones, dy3, 8, 2304, K, tn)])
+    torch.cuda.synchronize()
+    for (dy, x), got in zip(((dy1, x1), (dy2, x2), (dy3, x3)), outs[:3]):
+        sep = ops.gemm(dy, x, dy.shape[1], x.shape[1], K, tile=128, **tn)
+        assert torch.equal(got, sep)
+        _cmp(got, dy.float().cpu().t() @ x.float().cpu(), tol=2e-3)
+    for dy, got in ((dy1, outs[3]), (dy3, outs[4])):
+        assert got.shape[0] == 8 and torch.equal(got[0], got[7])
+        _cmp(got[0], dy.float().cpu().sum(0), tol=1e-3)
+
+
+def test_grouped_rejects_mixed_layouts():
+    from aptai_amd import ops, _lib
+    g = torch.Generator().manual_seed(12)
+    a, b = _rand((128, 64), g).cuda(), _rand((128, 64), g).cuda()
+    with pytest.raises(_lib.AptaiHipError):
+        ops.gemm_grouped([(a, b, 128, 128, 64, {}), (a, b, 64, 128, 128, dict(a_kmajor=True, b_kmajor=True, out_f32=True))])
 
 
 def test_bad_arguments_fail_loudly(ops):

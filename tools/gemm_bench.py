@@ -15,6 +15,10 @@ def bench(fn, iters=30):
     return e0.elapsed_time(e1) / iters * 1e3   # us
 
 def main():
+    tile = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    _g = ops.gemm
+    ops.gemm = lambda *a, **kw: _g(*a, tile=tile, **kw)
+    print(f"tile={tile}")
     M = 8192
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g).to(torch.bfloat16)
