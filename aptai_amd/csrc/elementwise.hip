@@ -14,6 +14,31 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __re
     }
 }
 
+// job table row: {src, dst, n (multiple of 8), kind}; kind 0: fp32 -> bf16, kind 1: fp32 -> fp32 copy.  grid (chunks, jobs):
+// every block converts one 8192-element chunk of its job, so the ~90 parameter casts of a train step are ONE launch.
+__global__ void cast_multi_kernel(const int64_t* __restrict__ table) {
+    const int64_t* job = table + (long)blockIdx.y * 4;
+    const long n = job[2];
+    const long base = (long)blockIdx.x * 8192;
+    if (base >= n) return;
+    const float* src = (const float*)job[0];
+    const bool copy = job[3] != 0;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const long i = base + (long)(it * 256 + threadIdx.x) * 8;
+        if (i >= n) break;
+        const f32x4 a = *(const f32x4*)(src + i), b = *(const f32x4*)(src + i + 4);
+        if (copy) {
+            float* dst = (float*)job[1];
+            *(f32x4*)(dst + i) = a;
+            *(f32x4*)(dst + i + 4) = b;
+        } else {
+            bf16_t* dst = (bf16_t*)job[1];
+            *(u32x4*)(dst + i) = (u32x4){pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+        }
+    }
+}
+
 // rows x cols fp32 -> bf16 with a destination leading dimension (packs q/k/v weights into one [3H][H] buffer)
 __global__ void cast_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long rows, long cols, long ldd) {
     const long n = rows * cols;
@@ -274,6 +299,14 @@ extern "C" int aptai_cast_f32_to_bf16(const float* src, void* dst, int64_t rows,
                            (bf16_t*)dst, (long)rows, (long)cols, (long)ld_dst);
     }
     APTAI_CHECK_LAUNCH("cast kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_cast_multi(const int64_t* table_dev, int64_t njobs, int64_t max_n, void* stream) {
+    APTAI_REQUIRE(table_dev && njobs > 0 && njobs <= 65535 && max_n > 0, "aptai_cast_multi: bad arguments");
+    const long chunks = ceil_div(max_n, 8192);
+    APTAI_LAUNCH(cast_multi_kernel, dim3((unsigned)chunks, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, table_dev);
+    APTAI_CHECK_LAUNCH("cast_multi_kernel");
     return APTAI_OK;
 }
 

@@ -142,24 +142,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// out[which][col] = sum_b partials[b][which][col].  block = 64 columns x 16 slices of the block list (1024 threads),
-// LDS combine: 32 loads per thread for 512 partial blocks.
+// out[which][col] = sum_b partials[b][which][col].  block = 16 columns x 64 slices of the block list (1024 threads): 96
+// blocks for 2 x 768 columns, 8 independent loads per thread for 512 partial blocks, fixed-order LDS combine.
 __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ partials, float* __restrict__ out0,
                                                                float* __restrict__ out1, int nblocks, int cols) {
-    __shared__ float red[16][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;              // index into the concatenated [2][cols] vector
+    __shared__ float red[64][17];
+    const int lc = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + lc;                // index into the concatenated [2][cols] vector
     float s = 0.f;
     if (c < 2 * cols) {
         const int which = c / cols, col = c % cols;
-        for (int b = slice; b < nblocks; b += 16) s += partials[((long)b * 2 + which) * cols + col];
+        const float* p = partials + (long)which * cols + col;
+#pragma unroll 8
+        for (int b = slice; b < nblocks; b += 64) s += p[(long)b * 2 * cols];
     }
-    red[slice][lane] = s;
+    red[slice][lc] = s;
     __syncthreads();
     if (slice == 0 && c < 2 * cols) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][lane];
+        for (int k = 0; k < 64; ++k) t += red[k][lc];
         float* o = (c / cols) ? out1 : out0;
         if (o) o[c % cols] = t;
     }
@@ -219,7 +221,7 @@ extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* m
     APTAI_CHECK_LAUNCH("ln_bwd_kernel");
     if (dgamma || dbeta) {
         const int n = 2 * (int)cols;
-        APTAI_LAUNCH(colsum_partials_kernel, dim3((n + 63) / 64), dim3(1024), 0, stream,
+        APTAI_LAUNCH(colsum_partials_kernel, dim3((n + 15) / 16), dim3(1024), 0, stream,
                            (const float*)workspace, dgamma, dbeta, (int)blocks, (int)cols);
         APTAI_CHECK_LAUNCH("colsum_partials_kernel");
     }

@@ -249,6 +249,34 @@ def cast_bf16(src: torch.Tensor, dst: Optional[torch.Tensor] = None, ld_dst: Opt
     return dst
 
 
+class CastPlan:
+    """A fixed list of (fp32 source, destination) pairs converted by ONE aptai_cast_multi launch.  The destinations are
+    persistent, so a plan replays unchanged inside a hipGraph; sources are re-read on every run (parameters move only
+    through in-place optimiser updates, so their addresses are stable; `stale()` detects re-allocated parameters)."""
+
+    def __init__(self, jobs):
+        # jobs: list of (src fp32 tensor, dst tensor [bf16 or fp32])
+        self.jobs = list(jobs)
+        rows = []
+        for src, dst in self.jobs:
+            _dev(src, dst)
+            n = src.numel()
+            if not (src.is_contiguous() and dst.is_contiguous() and src.dtype == torch.float32 and n == dst.numel() and n % 8 == 0
+                    and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0):
+                raise _lib.AptaiHipError("CastPlan: jobs must be contiguous, 16-byte aligned fp32 sources of n % 8 == 0 elements")
+            kind = {torch.bfloat16: 0, torch.float32: 1}[dst.dtype]
+            rows.append([src.data_ptr(), dst.data_ptr(), n, kind])
+        self.max_n = max(r[2] for r in rows)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(self.jobs[0][0].device)
+        self._src_ptrs = [r[0] for r in rows]
+
+    def stale(self) -> bool:
+        return any(src.data_ptr() != p for (src, _), p in zip(self.jobs, self._src_ptrs))
+
+    def run(self) -> None:
+        _lib.call("aptai_cast_multi", self.table.data_ptr(), len(self.jobs), self.max_n, _stream())
+
+
 def conv_weight_bf16(w: torch.Tensor) -> torch.Tensor:
     """[N][C][Kw] fp32 -> [N][Kw*C] bf16."""
     _dev(w)

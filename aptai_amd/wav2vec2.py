@@ -520,27 +520,59 @@ class Wav2Vec2Model(nn.Module):
         self._cache[key] = (ver, val)
         return val
 
-    def _layer_weights(self, i: int, M: int):
+    def _layer_params(self, i: int):
         l = self.encoder.layers[i]
         at, ff = l.attention, l.feed_forward
-        params = [at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, at.q_proj.bias, at.k_proj.bias, at.v_proj.bias,
-                  at.out_proj.weight, at.out_proj.bias, ff.intermediate_dense.weight, ff.intermediate_dense.bias,
-                  ff.output_dense.weight, ff.output_dense.bias]
-        H, I = self.config.hidden_size, self.config.intermediate_size
+        return [at.q_proj.weight, at.k_proj.weight, at.v_proj.weight, at.q_proj.bias, at.k_proj.bias, at.v_proj.bias,
+                at.out_proj.weight, at.out_proj.bias, ff.intermediate_dense.weight, ff.intermediate_dense.bias,
+                ff.output_dense.weight, ff.output_dense.bias]
 
-        def build():
-            dev = params[0].device
-            wqkv = torch.empty((3 * H, H), device=dev, dtype=torch.bfloat16)
+    def _layer_plan(self):
+        """Persistent bf16 copies of every transformer-layer weight (+ packed fp32 q/k/v biases) and the ONE-launch cast
+        plan (ops.CastPlan) that refreshes them: 12 layers x 9 jobs instead of ~90 separate cast / cat kernels."""
+        plan = getattr(self, "_lplan", None)
+        if plan is not None and not plan.stale():
+            return plan
+        H, I = self.config.hidden_size, self.config.intermediate_size
+        jobs, entries = [], []
+        for i in range(len(self.encoder.layers)):
+            p = self._layer_params(i)
+            dev = p[0].device
+            bf = lambda *shape: torch.empty(shape, device=dev, dtype=torch.bfloat16)
+            e = SimpleNamespace(wqkv=bf(3 * H, H), bqkv=torch.empty(3 * H, device=dev, dtype=torch.float32),
+                                wo=bf(H, H), w1=bf(I, H), w2=bf(H, I), bo=p[7].detach(), b1=p[9].detach(), b2=p[11].detach())
             for j in range(3):
-                ops.cast_bf16(params[j], wqkv[j * H:(j + 1) * H])
-            e = SimpleNamespace(wqkv=wqkv, bqkv=torch.cat([params[3], params[4], params[5]]).float().contiguous(),
-                                wo=ops.cast_bf16(params[6]), bo=params[7].detach().float(),
-                                w1=ops.cast_bf16(params[8]), b1=params[9].detach().float(),
-                                w2=ops.cast_bf16(params[10]), b2=params[11].detach().float())
-            return e
-        e = self._cached(("layer", i), params, build)
+                jobs.append((p[j].detach(), e.wqkv[j * H:(j + 1) * H]))
+                jobs.append((p[3 + j].detach(), e.bqkv[j * H:(j + 1) * H]))
+            jobs += [(p[6].detach(), e.wo), (p[8].detach(), e.w1), (p[10].detach(), e.w2)]
+            entries.append(e)
+        plan = ops.CastPlan(jobs)
+        plan.entries = entries
+        plan.version = None
+        self._lplan = plan
+        return plan
+
+    def _refresh_layer_copies(self, force: bool = False):
+        """Runs the cast plan when the copies may be stale.  Training mode: every forward (fused optimisers update
+        parameters in place without bumping Tensor._version, see _cached); eval mode: when a parameter version moved."""
+        mode = getattr(self, "_cache_mode", None)
+        if mode == "frozen":
+            return
+        plan = self._layer_plan()
+        params = [p for i in range(len(self.encoder.layers)) for p in self._layer_params(i)]
+        ver = self._versions(params)
+        trainable = self.training and any(p.requires_grad for p in params)
+        # an eval forward right after training must not trust the versions either (the last optimiser step is unseen)
+        if force or mode == "build" or trainable or plan.version != ver or getattr(plan, "after_training", False):
+            with torch.no_grad():
+                plan.run()
+            plan.version = ver
+            plan.after_training = bool(trainable)
+
+    def _layer_weights(self, i: int, M: int):
+        e = self._layer_plan().entries[i]
         e.split_k = self._split_k(M)
-        return e, params
+        return e, self._layer_params(i)
 
     def _split_k(self, M: int):
         """split-K factors for the four wgrad GEMMs (qkv, out, ffn1, ffn2): fill ~2 blocks per CU."""
@@ -751,6 +783,7 @@ class Wav2Vec2Model(nn.Module):
                    self.encoder.layer_norm.weight, self.encoder.layer_norm.bias]
         h = _run(front, feats, *fparams)
         # ---- transformer layers with LayerDrop (HF:694-707 / 767-780)
+        self._refresh_layer_copies()
         hidden = []
         for i, layer in enumerate(self.encoder.layers):
             hidden.append(h)

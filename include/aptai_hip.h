@@ -116,6 +116,9 @@ int aptai_attention_bwd(const void* qkv, const int32_t* lens, const void* ctx, c
 /* ------------------------------------------------------------------------------------------------ parameter prep
  * fp32 master parameters -> bf16 compute copies (and the layouts the kernels want). */
 int aptai_cast_f32_to_bf16(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_dst, void* stream);
+/* Many casts in one launch.  table_dev: device int64 [njobs][4] = {src fp32 ptr, dst ptr, n, kind}; n % 8 == 0, both
+ * pointers 32-/16-byte aligned; kind 0 = fp32 -> bf16, 1 = fp32 -> fp32 copy (packs q/k/v biases); max_n = largest n. */
+int aptai_cast_multi(const int64_t* table_dev, int64_t njobs, int64_t max_n, void* stream);
 /* nn.Conv1d weight [N][C][Kw] (HF:260-266) -> [N][Kw*C] bf16, K index = kw*C + c (channels-last frames) */
 int aptai_conv_weight_to_bf16(const float* src, void* dst, int64_t N, int64_t C, int64_t Kw, void* stream);
 /* positional conv (HF:329-356): weight_norm(dim=2) w = g*v/||v||_(0,1) ; v [H][H/groups][Kw], gain [Kw];
