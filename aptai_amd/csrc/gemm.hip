@@ -138,6 +138,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int wave_base_tid = wave * 64;
+    const bool wave_active = (m0 + wm * 64 < g.M) && (n0 + wn * 64 < g.N);
     if (nk > 0) {
         stage_operand<A_KM>(g.A, g.lda, m0, g.M, kt_begin * BK, smem, tid, wave_base_tid);
         stage_operand<B_KM>(g.B, g.ldb, n0, g.N, kt_begin * BK, smem + OPER_BYTES, tid, wave_base_tid);
@@ -153,18 +154,22 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
         }
         const char* sa = smem + cur * STAGE_BYTES;
         const char* sb = sa + OPER_BYTES;
+        // a wave whose 64 x 64 quadrant lies wholly outside the problem (grouped positional conv: 48 channels per group;
+        // bias-gradient problems: M = 8; heads: N = 64) stages and synchronises but issues no LDS reads and no MFMAs
+        if (wave_active) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[4];
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag<A_KM>(sa, wm * 64 + i * 16, ks, lane);
+                for (int i = 0; i < 4; ++i) af[i] = read_frag<A_KM>(sa, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<B_KM>(sb, wn * 64 + j * 16, ks, lane);
+                for (int j = 0; j < 4; ++j) bfr[j] = read_frag<B_KM>(sb, wn * 64 + j * 16, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
         }
     }
 
