@@ -41,7 +41,6 @@ def parse():
     ap.add_argument("--no-regularisers", action="store_true", help="dropout/LayerDrop/SpecAugment off (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)
-    ap.add_argument("--check-rmse", action="store_true", help="also report |RMSE_build - RMSE_oracle| on one small batch")
     ap.add_argument("--eager", action="store_true", help="drive the step through autograd (the drop-in loop) instead of hipGraphs")
     return ap.parse_args()
 
@@ -133,6 +132,39 @@ def cpu_baseline(args, cfg_gpu):
     return {"value": round(2 / t, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
             "sample": f"oracle APTAI train step (fp32 torch CPU restatement), wav2vec2-{args.model}, B=2 x {args.seconds:g} s, "
                       f"1 warm-up + {args.cpu_baseline_steps} timed steps, {t:.2f} s/step"}
+
+
+def ema_rmse_check(model, cfg, args, device):
+    """BASELINE metric's second half, "EMA RMSE vs ref": the same weights and one B=2 batch through the build (MI355X,
+    bf16, eval mode) and through the oracle (CPU fp32); tvs_metric_rmse (utility.py:393-418, mean over tracks) of each
+    against the synthetic targets, their difference, and the RMSE between the two predictions."""
+    import numpy as np
+    from oracle import heads_ref
+    from aptai_amd import hostlogic, metrics
+    S = int(16000 * args.seconds)
+    batch = synth_batch(cfg, 2, S, args.n_tv, 7, device)
+    names = [k for k in batch if k not in ("audio_inputs", "audio_lengths", "phn_frames_49hz")]
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        out = model(0, **batch)
+    pred_gpu = out["tvs_pred"].float().cpu().numpy()
+    model.train(was_training)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cb = {k: v.cpu() for k, v in batch.items()}
+    with torch.no_grad():
+        ref = heads_ref.aptai_forward(sd, cfg, cb["audio_inputs"], cb["audio_lengths"], cb["phn_frames_49hz"],
+                                      [cb[n] for n in names], training=False)
+    pred_ref = ref["tvs_pred"].numpy()
+    tgt = torch.stack([cb[n] for n in names], dim=-1).numpy()
+    valid = tgt[..., 0] != -100.0
+    g, a, b = tgt[valid], pred_gpu[valid], pred_ref[valid]
+    r_build = metrics.ema_rmse(g, a, names)
+    r_ref = metrics.ema_rmse(g, b, names)
+    return {"build": round(r_build, 6), "oracle": round(r_ref, 6), "abs_diff": float(f"{abs(r_build - r_ref):.3e}"),
+            "rmse_between_predictions": float(f"{float(np.sqrt(np.mean((a - b) ** 2))):.3e}"),
+            "sample": f"eval forward, B=2 x {args.seconds:g} s, {len(names)} tracks, {int(valid.sum())} valid frames, same weights; "
+                      "tvs_metric_rmse averaged over tracks (utility.py:393-418)"}
 
 
 def main():
@@ -241,7 +273,7 @@ def main():
                        "optimizer": "Adam (torch fused, fp32 state)",
                        "execution": "eager autograd loop" if args.eager else "hipGraph segments (aptai_amd.graphed)"},
             "loss": round(loss, 5),
-            "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM, NT layout (gemm_kernel<false,false,false> + gemm256_kernel<false,false,false>): every launch of the step",
+            "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM, NT layout (gemm_kernel / gemm192_kernel / gemm256_kernel <false,false,false>): every launch of the step",
                          "achieved": round(gemm_tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / 2500.0, 4), "traffic": traffic,
                          "traffic_note": "HBM-side bytes per launch, rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, separate passes), "
@@ -252,6 +284,7 @@ def main():
         }
         res["config"].pop("frames_per_clip")
         if world == 1 and not args.no_cpu_baseline:
+            res["ema_rmse_vs_ref"] = ema_rmse_check(model, cfg, args, device)
             res["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -351,7 +351,40 @@ def case_ops(name="ops_small"):
     save(name, dict(case=name), arrays)
 
 
-CASES = {"ops": case_ops, "pr_mini": case_pr_base_mini, "pr_base": case_pr_base, "aptai_large": case_aptai_large,
+def case_metrics(name="metrics_small"):
+    """utility.py metrics as validate()/test() call them (train/train_aptai.py:577-609): per-track RMSE / Pearson,
+    boundary P/R/F1/R-value, frame overlap, run-length helpers.  compute_PER needs the absent editdistance package."""
+    import utility as ref_util
+    arrays = {}
+    rng = np.random.RandomState(5)
+    gt = rng.randn(700, 9)
+    pred = gt * 0.8 + 0.3 * rng.randn(700, 9) + 0.05
+    arrays["tv/gt"], arrays["tv/pred"] = gt, pred
+    rm = ref_util.tvs_metric_rmse(gt, pred)
+    pc = ref_util.tvs_metric_ppc(gt, pred)
+    arrays["tv/rmse"] = np.array([rm[k] for k in TV])
+    arrays["tv/pcc_r"] = np.array([pc[k][0] for k in TV])
+    arrays["tv/pcc_p"] = np.array([pc[k][1] for k in TV])
+    for i, (ny, nh) in enumerate([(40, 37), (5, 9), (1, 1)]):
+        y = np.sort(rng.uniform(0, 10, ny))
+        yh = np.sort(np.concatenate([y[:min(ny, nh) // 2] + rng.uniform(-0.03, 0.03, min(ny, nh) // 2),
+                                     rng.uniform(0, 10, nh - min(ny, nh) // 2)]))
+        arrays[f"seg/{i}/y"], arrays[f"seg/{i}/yhat"] = y, yh
+        arrays[f"seg/{i}/prf"] = np.array([float(v) for v in ref_util.get_stats(y, yh, tolerance=0.02)])
+    arrays["seg/metrics_in"] = np.array([13.0, 11.0, 20.0, 17.0])
+    arrays["seg/metrics_out"] = np.array([float(v) for v in ref_util.get_metrics(13, 11, 20, 17)])
+    frames = [rng.randint(1, 6, n).repeat(rng.randint(1, 5, n)) for n in (30, 12, 1)]
+    preds = [np.where(rng.rand(len(f)) < 0.8, f, rng.randint(1, 6, len(f))) for f in frames]
+    arrays["ovl/value"] = np.float64(ref_util.evaluate_overlap([f.tolist() for f in frames], [p.tolist() for p in preds]))
+    for i, (f, p) in enumerate(zip(frames, preds)):
+        arrays[f"ovl/{i}/gt"], arrays[f"ovl/{i}/pred"] = f, p
+        arrays[f"rle/{i}/phn"] = np.array(ref_util.phn_frame_id2phn(f.tolist()))
+        d = ref_util.phn_frames2dur(f.tolist())
+        arrays[f"rle/{i}/dur"] = np.array([[a, b, c] for a, b, c in d], dtype=np.float64)
+    save(name, dict(case=name), arrays)
+
+
+CASES = {"ops": case_ops, "metrics": case_metrics, "pr_mini": case_pr_base_mini, "pr_base": case_pr_base, "aptai_large": case_aptai_large,
          "force": case_force}
 
 if __name__ == "__main__":
