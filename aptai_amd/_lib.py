@@ -16,7 +16,8 @@ import torch  # noqa: F401  -- MUST precede the CDLL below: torch's bundled HIP 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libaptai_hip.so")
+# APTAI_HIP_LIB: A/B a second in-tree build of the same sources (tools/, never a different implementation)
+LIB_PATH = os.environ.get("APTAI_HIP_LIB") or os.path.join(CSRC, "libaptai_hip.so")
 
 _lib = None
 _lock = threading.Lock()

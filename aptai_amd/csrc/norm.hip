@@ -3,6 +3,8 @@
 // HF:587-601 / 622-644 (encoder layers), HF:691 / 791 (encoder LN) and models/modules.py:134,151.
 // HBM-bound: one wave64 per row, 8-byte vector loads, statistics in fp32 with wave shuffles, no LDS
 // on the forward path.  Algorithmic bytes/row: 2*cols in + 2*cols out (+8 for mean/rstd).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -167,7 +169,17 @@ __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __re
     }
 }
 
-constexpr int LN_BWD_MAX_BLOCKS = 512;
+constexpr int LN_BWD_MAX_BLOCKS_DEFAULT = 512;
+static long ln_bwd_max_blocks() {
+    static long v = 0;
+    if (v == 0) {
+        const char* e = getenv("APTAI_LN_BWD_BLOCKS");          // tuning knob (tools/ln_bench.py)
+        v = e ? atol(e) : LN_BWD_MAX_BLOCKS_DEFAULT;
+        if (v < 1) v = LN_BWD_MAX_BLOCKS_DEFAULT;
+    }
+    return v;
+}
+#define LN_BWD_MAX_BLOCKS ln_bwd_max_blocks()
 
 }  // namespace
 
