@@ -251,9 +251,9 @@ def main():
         traffic = None
         try:                 # PMC traffic of the dominant kernel, collected offline (tools/pmc_summary.py), bytes per launch
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            for k, v in pm.items():
-                if "gemm_kernel<false, false, false>" in k:
-                    traffic = v["hbm_bytes_per_launch_corrected"]
+            nt = [v for k, v in pm.items() if "<false, false, false>" in k and "gemm" in k]      # the NT family the probe brackets
+            traffic = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_in_trace"] for v in nt) /
+                          max(sum(v["launches_in_trace"] for v in nt), 1))
         except Exception:
             pass
         gf = FWD_GF.get((args.model, args.seconds))
@@ -276,8 +276,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM, NT layout (gemm_kernel / gemm192_kernel / gemm256_kernel <false,false,false>): every launch of the step",
                          "achieved": round(gemm_tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / 2500.0, 4), "traffic": traffic,
-                         "traffic_note": "HBM-side bytes per launch, rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, separate passes), "
-                                         "profiles/r01_pmc_traffic.json",
+                         "traffic_note": "HBM-side bytes per launch, launch-weighted over the same NT kernels, rocprofv3 PMC (2 x FETCH_SIZE + "
+                                         "WRITE_SIZE, separate passes), profiles/r01_pmc_traffic.json",
                          "measured": probe_note, "launches": ps["launches"], "avg_launch_us": round(ps["ms"] * 1e3 / max(ps["launches"], 1), 2),
                          "step_algorithmic_tflop": step_tf,
                          "whole_step_frac_of_peak": round(step_tf / (dt / args.steps) / 2500.0, 4) if step_tf else None},
