@@ -136,6 +136,57 @@ class GradBucketReducer:
         self._hooks = []
 
 
+class GradGroupReducer:
+    """All-reduce (average) of explicit groups of gradient tensors, for manually driven backward passes
+    (aptai_amd.graphed): `launch(key, tensors)` right after the graph segment that produced them — the collective runs
+    on a side stream under the next segment's kernels — and `finish()` before the optimiser step.  One flat
+    communication buffer per key (bf16 by default: a 12-layer base model is 12 x 14 MB + front/heads), so a layer is one
+    collective of a size xGMI moves in ~0.2 ms while the next layer's backward takes ~0.6 ms."""
+
+    def __init__(self, comm_dtype: Optional[torch.dtype] = torch.bfloat16, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.comm_dtype = comm_dtype
+        self._flat = {}
+        self._pending = []
+        self._stream = None
+
+    def launch(self, key, tensors: List[torch.Tensor]) -> None:
+        if self.world == 1 or not tensors:
+            return
+        n = sum(t.numel() for t in tensors)
+        dt = self.comm_dtype or tensors[0].dtype
+        flat = self._flat.get(key)
+        if flat is None or flat.numel() != n or flat.device != tensors[0].device or flat.dtype != dt:
+            flat = torch.empty(n, device=tensors[0].device, dtype=dt)
+            self._flat[key] = flat
+        views, off = [], 0
+        for t in tensors:
+            views.append(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        if flat.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                torch._foreach_copy_(views, tensors)
+                h = dist.all_reduce(flat, group=self.group, async_op=True)
+        else:
+            torch._foreach_copy_(views, tensors)
+            h = dist.all_reduce(flat, group=self.group, async_op=True)
+        self._pending.append((h, views, tensors))
+
+    def finish(self) -> None:
+        inv = 1.0 / self.world
+        for h, views, tensors in self._pending:
+            h.wait()
+            if views[0].is_cuda:
+                torch.cuda.current_stream().wait_stream(self._stream)
+            torch._foreach_copy_(tensors, views)
+            torch._foreach_mul_(tensors, inv)
+        self._pending = []
+
+
 def shard_batch(batch: dict, rank: int, world: int) -> dict:
     """Contiguous utterance shards of a global batch dict."""
     out = {}

@@ -32,6 +32,11 @@ class GraphedAPTAIStep:
     def __init__(self, model: APTAI, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], reducer=None):
         assert model.training, "call model.train() first"
         self.model, self.opt, self.reducer = model, optimizer, reducer
+        # data parallel: gradients are averaged per graph segment (dp.GradGroupReducer), overlapped with the next segment
+        self.group_reducer = None
+        if reducer is not None and getattr(reducer, "world", 1) > 1:
+            from .dp import GradGroupReducer
+            self.group_reducer = GradGroupReducer(comm_dtype=reducer.comm_dtype, process_group=reducer.group)
         w = model.wav2vec2
         self.w, self.cfg = w, w.config
         cfg = self.cfg
@@ -193,13 +198,21 @@ class GraphedAPTAIStep:
                 self.g_fwd[i].replay()
             else:
                 self.X[i + 1].copy_(self.X[i])
+        red = self.group_reducer
         self.g_tail.replay()
+        if red is not None:
+            red.launch("heads", [gt for p, gt in self.grads.items() if p.requires_grad and any(p is q for q in self.hparams)])
         for i in range(L - 1, -1, -1):
             if keep[i]:
                 self.g_bwd[i].replay()
+                if red is not None:            # layer i's gradients travel while layer i-1's backward runs
+                    red.launch(("layer", i), self._layer_grad_tensors(i))
             else:
                 self.dX[i].copy_(self.dX[i + 1])
         self.g_front_bwd.replay()
+        if red is not None:
+            red.launch("front", [gt for p, gt in self.grads.items() if p.requires_grad and not any(p is q for q in self.hparams)])
+            red.finish()
         for p, gt in self.grads.items():
             if p.requires_grad:
                 p.grad = gt
@@ -207,8 +220,6 @@ class GraphedAPTAIStep:
             for p, gt in self.layer_grads[i]:
                 if p.requires_grad:
                     p.grad = gt if keep[i] else None
-        if self.reducer is not None:
-            self.reducer.reduce_existing_grads()
         if not getattr(self, "_checked", False):
             names = {id(p): n for n, p in self.model.named_parameters()}
             for p in self.model.parameters():
@@ -220,6 +231,18 @@ class GraphedAPTAIStep:
         self.opt.step()
         loss, mse, ce, tvs, pred, _ = self.outs
         return {"loss": loss, "mse_loss": mse, "ce_loss": ce, "tvs_pred": tvs, "phn_fc_pred": pred}
+
+    def _layer_grad_tensors(self, i: int) -> List[torch.Tensor]:
+        """Distinct gradient buffers of layer i (the q/k/v weight and bias gradients are row slices of one buffer each)."""
+        out, seen = [], set()
+        for p, gt in self.layer_grads[i]:
+            if not p.requires_grad:
+                continue
+            base = gt._base if gt._base is not None else gt
+            if base.data_ptr() not in seen:
+                seen.add(base.data_ptr())
+                out.append(base)
+        return out
 
     def close(self):
         """Back to the eager loop: drop the per-step salt and the frozen weight cache."""

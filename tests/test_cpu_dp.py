@@ -80,6 +80,49 @@ def test_dp_gradients_equal_single_process(comm_bf16):
         assert (res[0][n] == res[1][n]).all()            # replicas stay bit-identical
 
 
+def _group_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aptai_amd.dp import GradGroupReducer
+    red = GradGroupReducer(comm_dtype=None)
+    g = torch.Generator().manual_seed(100 + rank)
+    base = torch.randn(6, 5, generator=g)
+    groups = {"a": [torch.randn(4, 3, generator=g), torch.randn(7, generator=g)], "b": [base]}
+    for step in range(2):                                    # flat buffers are reused across steps
+        for k, ts in groups.items():
+            red.launch(k, ts)
+        red.finish()
+    q.put((rank, {k: [t.numpy().copy() for t in ts] for k, ts in groups.items()}))
+    dist.destroy_process_group()
+
+
+def test_group_reducer_averages_explicit_tensor_groups():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # two averaging rounds of values that are already equal after the first: result = mean of the two ranks' tensors
+    import numpy as np
+    ref = {}
+    for rank in range(world):
+        g = torch.Generator().manual_seed(100 + rank)
+        base = torch.randn(6, 5, generator=g)
+        ref[rank] = {"a": [torch.randn(4, 3, generator=g), torch.randn(7, generator=g)], "b": [base]}
+    for k in ("a", "b"):
+        for j in range(len(ref[0][k])):
+            want = ((ref[0][k][j] + ref[1][k][j]) / 2).numpy()
+            for r in range(world):
+                np.testing.assert_allclose(res[r][k][j], want, rtol=1e-6, atol=1e-7)
+
+
 def test_shard_batch_is_contiguous():
     from aptai_amd.dp import shard_batch
     b = {"a": torch.arange(8), "b": torch.arange(16).view(8, 2)}
