@@ -1,7 +1,7 @@
 // First layer of the wav2vec2 feature encoder on the raw waveform (HF:260-266 conv, C_in=1 -> 512, k=10, s=5),
 // fused with its normalisation and GELU so the 32.8 MB/utterance (10 s) activation is written exactly once:
 //   mode 0 "group": GroupNorm(512 groups of 1 channel) over all T0 frames (HF:317-323, wav2vec2-base)
-//                   -> pass 1 recomputes the conv to get per-(utterance, channel) statistics, pass 2 writes.
+//                   -> per-(utterance, channel) statistics from 65 window moments of the waveform, then ONE conv pass writes.
 //   mode 1 "layer": LayerNorm(512) over channels per frame (HF:288-299, wav2vec2-large), single pass.
 // HBM-bound by the output write (512 ch x 2 B per frame; the waveform read is 20 B per frame).
 // One wave per frame, lane = 8 consecutive channels (16-byte coalesced stores); weights live in registers.
@@ -85,47 +85,75 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args a) {
     }
 }
 
-// ---- mode 0 pass 1: per-chunk partial sums of the conv output.  grid (nchunks, B)
-__global__ __launch_bounds__(256) void conv0_stats_kernel(Conv0Args a) {
-    __shared__ float red[4][2][C0];
+// ---- mode 0 statistics WITHOUT a conv pass.  y_c[t] = b_c + sum_k w_c[k] x[5t+k], so over the frames of one utterance
+//   mean_t y_c   = b_c + w_c . m                      m[k]     = mean_t x[5t+k]
+//   mean_t y_c^2 = w_c^T R w_c + 2 b_c (w_c . m) + b_c^2   R[k][k'] = mean_t x[5t+k] x[5t+k']
+// i.e. the 512 channel statistics are quadratic forms in 10 + 55 window moments of the waveform: 65 FMAs per frame
+// instead of 5120 (the recompute pass this replaces took 107 us of the 420 us the first layer cost at 16 x 10 s).
+constexpr int AC_TERMS = KW + KW * (KW + 1) / 2;        // 65
+constexpr int AC_FRAMES_PER_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ audio, long S, int T_real,
+                                                            float* __restrict__ partials, int nch) {
+    __shared__ float red[4][AC_TERMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y, chunk = blockIdx.x;
-    float w[8][KW], bias[8];
-    load_weights(a, lane, w, bias);
-    const float* xb = a.audio + (long)b * a.S;
-    float s1[8], s2[8];
+    const float* xb = audio + (long)b * S;
+    float acc[AC_TERMS];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-    const int t0 = chunk * FRAMES_PER_BLOCK_STATS;
-    int t1 = t0 + FRAMES_PER_BLOCK_STATS;
-    t1 = t1 < a.T_real ? t1 : a.T_real;
-    for (int t = t0 + wave; t < t1; t += 4) {
-        float v[8];
-        conv_frame(xb + (long)t * STRIDE, w, bias, v);
+    for (int i = 0; i < AC_TERMS; ++i) acc[i] = 0.f;
+    const int t0 = chunk * AC_FRAMES_PER_BLOCK;
+    int t1 = t0 + AC_FRAMES_PER_BLOCK;
+    t1 = t1 < T_real ? t1 : T_real;
+    for (int t = t0 + threadIdx.x; t < t1; t += 256) {
+        float x[KW];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+        for (int k = 0; k < KW; ++k) x[k] = xb[(long)t * STRIDE + k];
+        int idx = KW;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+            acc[k] += x[k];
+#pragma unroll
+            for (int k2 = k; k2 < KW; ++k2) { acc[idx] = fmaf(x[k], x[k2], acc[idx]); ++idx; }
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[wave][0][lane * 8 + j] = s1[j]; red[wave][1][lane * 8 + j] = s2[j]; }
+    for (int i = 0; i < AC_TERMS; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C0; i += 256) {
-        const int which = i / C0, c = i % C0;
-        a.partials[(((long)b * a.nchunks + chunk) * 2 + which) * C0 + c] =
-            red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
-    }
+    if (threadIdx.x < AC_TERMS)
+        partials[((long)b * nch + chunk) * AC_TERMS + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// ---- mode 0 finalize: mean / rstd per (b, c), combined in double.  grid (B), 512 threads
-__global__ void conv0_stats_final_kernel(const float* __restrict__ partials, float* __restrict__ stats, int nchunks,
-                                         int T_real, float eps) {
+// mean / rstd per (b, c) from the window moments, in double.  grid (B), 512 threads
+__global__ void conv0_moments_final_kernel(const float* __restrict__ partials, const float* __restrict__ w,
+                                           const float* __restrict__ bias, float* __restrict__ stats, int nch, int T_real,
+                                           float eps) {
+    __shared__ double mom[AC_TERMS];
     const int b = blockIdx.x, c = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-        s1 += (double)partials[(((long)b * nchunks + k) * 2 + 0) * C0 + c];
-        s2 += (double)partials[(((long)b * nchunks + k) * 2 + 1) * C0 + c];
+    if (c < AC_TERMS) {
+        double s = 0.0;
+        for (int k = 0; k < nch; ++k) s += (double)partials[((long)b * nch + k) * AC_TERMS + c];
+        mom[c] = s / T_real;
     }
-    const double mean = s1 / T_real;
-    double var = s2 / T_real - mean * mean;
+    __syncthreads();
+    double wk[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) wk[k] = (double)w[c * KW + k];
+    const double bc = bias ? (double)bias[c] : 0.0;
+    double wm = 0.0, q = 0.0;
+    int idx = KW;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        wm += wk[k] * mom[k];
+#pragma unroll
+        for (int k2 = k; k2 < KW; ++k2) q += (k2 == k ? 1.0 : 2.0) * wk[k] * wk[k2] * mom[idx++];
+    }
+    const double mean = bc + wm;
+    double var = q + 2.0 * bc * wm + bc * bc - mean * mean;
     var = var < 0.0 ? 0.0 : var;
     stats[((long)b * 2 + 0) * C0 + c] = (float)mean;
     stats[((long)b * 2 + 1) * C0 + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -380,11 +408,13 @@ extern "C" int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const f
     a.partials = (float*)workspace;
     float* stats = stats_out ? stats_out : (float*)workspace + (long)B * a.nchunks * 2 * C0;
     a.stats = stats;
-    APTAI_LAUNCH(conv0_stats_kernel, dim3((unsigned)a.nchunks, (unsigned)B), dim3(256), 0, stream, a);
-    APTAI_CHECK_LAUNCH("conv0_stats_kernel");
-    APTAI_LAUNCH(conv0_stats_final_kernel, dim3((unsigned)B), dim3(C0), 0, stream, (const float*)a.partials, stats,
-                       a.nchunks, (int)T_real, eps);
-    APTAI_CHECK_LAUNCH("conv0_stats_final_kernel");
+    const int nch = (int)ceil_div(T_real, AC_FRAMES_PER_BLOCK);   // [B][nch][65] floats: fits the conv-pass workspace
+    APTAI_LAUNCH(conv0_moments_kernel, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, stream, audio, (long)S, (int)T_real,
+                 a.partials, nch);
+    APTAI_CHECK_LAUNCH("conv0_moments_kernel");
+    APTAI_LAUNCH(conv0_moments_final_kernel, dim3((unsigned)B), dim3(C0), 0, stream, (const float*)a.partials, weight, bias,
+                 stats, nch, (int)T_real, eps);
+    APTAI_CHECK_LAUNCH("conv0_moments_final_kernel");
     APTAI_LAUNCH(conv0_group_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, a);
     APTAI_CHECK_LAUNCH("conv0_group_kernel");
     return APTAI_OK;
