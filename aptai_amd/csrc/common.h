@@ -107,7 +107,7 @@ __device__ __forceinline__ float erf_fast(float x) {
 __device__ __forceinline__ float gelu_sig(float xc, float x2) {      // Phi(xc), xc clamped, x2 = xc*xc
     float p = fmaf(APTAI_GELU_A5 * APTAI_NLOG2E, x2, APTAI_GELU_A3 * APTAI_NLOG2E);
     p = fmaf(p, x2, APTAI_GELU_A1 * APTAI_NLOG2E);
-    return __frcp_rn(1.0f + __builtin_amdgcn_exp2f(xc * p));
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xc * p));     // bare v_rcp_f32 (1 ulp); __frcp_rn expands to the 10-instruction IEEE divide
 }
 __device__ __forceinline__ float gelu_fast(float x) {
     const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
