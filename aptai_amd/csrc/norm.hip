@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 }
 
 // dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)) [+ dres];  partial dgamma/dbeta per block.
-template <int NCH>
+template <int NCH, bool GELU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const bf16_t* __restrict__ dres,
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const f32x4 g4 = *(const f32x4*)(gamma + (j * 64 + lane) * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { gm[j][r] = g4[r]; dg[j][r] = 0.f; db[j][r] = 0.f; bt[j][r] = 0.f; }
-        if (beta_gelu) {
+        if (GELU) {
             const f32x4 b4 = *(const f32x4*)(beta_gelu + (j * 64 + lane) * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bt[j][r] = b4[r];
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 xh[j][r] = (xv[r] - mu) * rs;
-                if (beta_gelu) dv[r] *= gelu_fast_grad(fmaf(xh[j][r], gm[j][r], bt[j][r]));   // y = gelu(LN(x)): fold gelu' into dy
+                if (GELU) dv[r] *= gelu_fast_grad(fmaf(xh[j][r], gm[j][r], bt[j][r]));   // y = gelu(LN(x)): fold gelu' into dy
                 gd[j][r] = dv[r] * gm[j][r];
                 s1 += gd[j][r];
                 s2 += gd[j][r] * xh[j][r];
@@ -122,8 +122,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             if (dx_drop) {
                 float m[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    m[r] = drop_keep((uint64_t)off + r, seed0, seed1, thr16) ? o[r] * dscale : 0.f;
+                for (int r = 0; r < 4; r += 2) {                   // off is a multiple of 4: one hash per element pair
+                    const uint32_t hsh = drop_hash_pair((uint64_t)off + r, seed0, seed1);
+                    m[r] = (hsh & 0xffffu) >= thr16 ? o[r] * dscale : 0.f;
+                    m[r + 1] = (hsh >> 16) >= thr16 ? o[r + 1] * dscale : 0.f;
+                }
                 *(u32x2*)(dx_drop + off) = (u32x2){pack2bf(m[0], m[1]), pack2bf(m[2], m[3])};
             }
         }
@@ -222,13 +225,15 @@ extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* m
     const uint32_t thr = drop_thr16(dropout_p);
     void* dxd = thr ? dx_drop : nullptr;
     if (dx_drop && !thr) APTAI_FAIL(APTAI_ERR_INVALID, "aptai_layernorm_bwd: dx_drop given with dropout_p == 0");
-#define LN_BWD(NCH) APTAI_LAUNCH(ln_bwd_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows, beta_if_gelu_after, aptai_seed_salt())
+#define LN_BWD_G(NCH, G) APTAI_LAUNCH((ln_bwd_kernel<NCH, G>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows, beta_if_gelu_after, aptai_seed_salt())
+#define LN_BWD(NCH) do { if (beta_if_gelu_after) LN_BWD_G(NCH, true); else LN_BWD_G(NCH, false); } while (0)
     switch (cols / 256) {
         case 1: LN_BWD(1); break;
         case 2: LN_BWD(2); break;
         case 3: LN_BWD(3); break;
         default: LN_BWD(4); break;
     }
+#undef LN_BWD_G
 #undef LN_BWD
     APTAI_CHECK_LAUNCH("ln_bwd_kernel");
     if (dgamma || dbeta) {
