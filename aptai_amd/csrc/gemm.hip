@@ -22,11 +22,6 @@ namespace {
 #ifndef APTAI_GEMM_HOIST
 #define APTAI_GEMM_HOIST 1
 #endif
-// 32x32x16 MFMA path of the NT variant: correct (tests pass with -DAPTAI_GEMM_MFMA32=1) but measured 10-20 % SLOWER than
-// 16x16x32 on every hot-path shape (8192x768x3072: 56.6 vs 46.4 us), so it stays off.
-#ifndef APTAI_GEMM_MFMA32
-#define APTAI_GEMM_MFMA32 0
-#endif
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int NTHREADS = 256;
 constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;   // 32 KiB
@@ -51,7 +46,6 @@ struct GemmArgs {
     int ktiles_per_split;
     long slab_stride;           // elements between split-K slabs (fp32 out only)
     int tiles_m, tiles_n;
-    int stagger;                // x 2048 cycles initial delay of the second block slot (heavy epilogues only)
     // 2-level batching: blockIdx.y = outer * nb_inner + inner; element offsets per level
     int nb_inner;
     long sA[2], sB[2], sC[2], sBias[2], sR[2], sAux[2];
@@ -60,13 +54,7 @@ struct GemmArgs {
 __device__ __forceinline__ int km_swz(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
 
 // ---- global -> LDS staging of one operand tile (1024 x 16-B chunks, 4 per thread)
-// K-contiguous tiles: 16-B chunk c of row r sits at chunk position c ^ kc_swz(r).  SW32 = the variant for 32-row MFMA
-// fragments (v_mfma_f32_32x32x16): a ds_read_b128 lane group then covers rows {0-3,12-15,20-27} or {4-11,16-19,28-31} of the
-// fragment, and (r >> 1) & 7 is distinct over the even rows (and over the odd rows) of either set - with r & 7 it is not.
-template <bool SW32>
-__device__ __forceinline__ int kc_swz(int row) { return SW32 ? ((row >> 1) & 7) : (row & 7); }
-
-template <bool KM, bool SW32 = false>
+template <bool KM>
 __device__ __forceinline__ void stage_operand(const bf16_t* __restrict__ base, long ld, int row0, int rows_total,
                                               int k0, char* lds_tile, int tid, int wave_base_tid) {
 #pragma unroll
@@ -77,7 +65,7 @@ __device__ __forceinline__ void stage_operand(const bf16_t* __restrict__ base, l
             const int row = cid >> 3, pc = cid & 7;
             int grow = row0 + row;
             grow = grow < rows_total ? grow : rows_total - 1;
-            src = base + (long)grow * ld + k0 + ((pc ^ kc_swz<SW32>(row)) << 3);
+            src = base + (long)grow * ld + k0 + ((pc ^ (row & 7)) << 3);
         } else {
             const int krow = cid >> 4, pc = cid & 15;
             int col = row0 + ((pc ^ km_swz(krow)) << 3);
@@ -118,13 +106,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // one 128 x 128 output tile: `bid` is the (already remapped) tile index of problem g, `batch` < 0 = not batched
-// 32 rows x 16 k fragment of a K-contiguous tile for v_mfma_f32_32x32x16_bf16: lane -> row (lane & 31), k = 8 (lane >> 5) + j
-__device__ __forceinline__ bf16x8 read_frag32(const char* lds_tile, int row_base, int ks, int lane) {
-    const int row = row_base + (lane & 31);
-    const int q = ks * 2 + (lane >> 5);
-    return *(const bf16x8*)(lds_tile + row * 128 + ((q ^ kc_swz<true>(row)) << 4));
-}
-
 template <bool A_KM, bool B_KM, bool OUT_F32>
 __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const int batch, const int split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -153,26 +134,17 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     kt_end = kt_end < total_kt ? kt_end : total_kt;
     const int nk = kt_end - kt_begin;
 
-    // NT (both operands K-contiguous): 2 x 2 tiles of v_mfma_f32_32x32x16 per wave - 16 MFMAs of 32 cycles per K-tile
-    // instead of 32 of 16, i.e. half the MFMA issue slots, which the two waves of a SIMD need for LDS reads and staging.
-    // K-major variants keep 16x16x32 (their fragments come from ds_read_b64_tr_b16 in the 16-row layout).
-    constexpr bool MF32 = !A_KM && !B_KM && APTAI_GEMM_MFMA32;
     f32x4 acc[4][4];
-    f32x16 acc32[2][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc32[i][j] = (f32x16)(0.f);
 
     const int wave_base_tid = wave * 64;
     const bool wave_active = (m0 + wm * 64 < g.M) && (n0 + wn * 64 < g.N);
     if (nk > 0) {
-        stage_operand<A_KM, MF32>(g.A, g.lda, m0, g.M, kt_begin * BK, smem, tid, wave_base_tid);
-        stage_operand<B_KM, MF32>(g.B, g.ldb, n0, g.N, kt_begin * BK, smem + OPER_BYTES, tid, wave_base_tid);
+        stage_operand<A_KM>(g.A, g.lda, m0, g.M, kt_begin * BK, smem, tid, wave_base_tid);
+        stage_operand<B_KM>(g.B, g.ldb, n0, g.N, kt_begin * BK, smem + OPER_BYTES, tid, wave_base_tid);
     }
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -180,32 +152,15 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
         const int cur = kt & 1;
         if (kt + 1 < nk) {
             char* nxt = smem + (cur ^ 1) * STAGE_BYTES;
-            stage_operand<A_KM, MF32>(g.A, g.lda, m0, g.M, (kt_begin + kt + 1) * BK, nxt, tid, wave_base_tid);
-            stage_operand<B_KM, MF32>(g.B, g.ldb, n0, g.N, (kt_begin + kt + 1) * BK, nxt + OPER_BYTES, tid, wave_base_tid);
+            stage_operand<A_KM>(g.A, g.lda, m0, g.M, (kt_begin + kt + 1) * BK, nxt, tid, wave_base_tid);
+            stage_operand<B_KM>(g.B, g.ldb, n0, g.N, (kt_begin + kt + 1) * BK, nxt + OPER_BYTES, tid, wave_base_tid);
         }
         const char* sa = smem + cur * STAGE_BYTES;
         const char* sb = sa + OPER_BYTES;
         // a wave whose 64 x 64 quadrant lies wholly outside the problem (grouped positional conv: 48 channels per group;
         // bias-gradient problems: M = 8; heads: N = 64) stages and synchronises but issues no LDS reads and no MFMAs
         if (wave_active) {
-            if constexpr (MF32) {
-                bf16x8 a32[4][2], b32[4][2];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        b32[ks][t] = read_frag32(sb, wn * 64 + t * 32, ks, lane);
-                        a32[ks][t] = read_frag32(sa, wm * 64 + t * 32, ks, lane);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                        for (int tj = 0; tj < 2; ++tj)
-                            acc32[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b32[ks][tj], a32[ks][ti], acc32[ti][tj], 0, 0, 0);
-            } else if constexpr (!A_KM && !B_KM && APTAI_GEMM_HOIST) {
+            if constexpr (!A_KM && !B_KM && APTAI_GEMM_HOIST) {
                 // K-contiguous operands: all 16 ds_read_b128 of the K-tile are issued before the first MFMA (sched_barrier
                 // keeps the compiler from sinking them next to their uses): one exposed LDS latency per K-tile instead of
                 // one per fragment group (+9 % at K = 3072).  With transposing reads (K-major operands) the same hoist
@@ -266,22 +221,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
         }
     }
     __syncthreads();                                   // every wave is done reading the staging buffers
-    if constexpr (MF32) {
-        // acc32[ti][tj][r]: m = wm*64 + ti*32 + (lane&31);  n = wn*64 + tj*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)
-        char* ct = smem;
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            const int ml = wm * 64 + ti * 32 + (lane & 31);
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int nl = wn * 64 + tj * 32 + 8 * g4 + 4 * (lane >> 5);
-                    *(f32x4*)(ct + ml * EPI_PITCH + nl * 4) = (f32x4){acc32[ti][tj][4 * g4], acc32[ti][tj][4 * g4 + 1],
-                                                                       acc32[ti][tj][4 * g4 + 2], acc32[ti][tj][4 * g4 + 3]};
-                }
-        }
-    } else {
+    {
         char* ct = smem;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -359,11 +299,6 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
 
 template <bool A_KM, bool B_KM, bool OUT_F32>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
-    // Phase stagger: the first 256 blocks take one slot of every CU, blocks 256..511 the second.  Delaying the second
-    // slot once puts the two co-resident blocks of a CU out of phase for the rest of the launch (each block is replaced
-    // when it finishes), so the VALU-heavy epilogue of one overlaps the MFMA main loop of the other.
-    if (g.stagger && blockIdx.x >= 256 && blockIdx.x < 512 && gridDim.x > 512)
-        for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(32);
     gemm_tile_body<A_KM, B_KM, OUT_F32>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), gridDim.y > 1 ? (int)blockIdx.y : -1,
                                         blockIdx.z);
 }
@@ -1049,14 +984,6 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
         APTAI_REQUIRE((size_t)d->workspace_bytes >= (size_t)nsplit * d->M * d->N * 4, "aptai_gemm_bf16: workspace too small");
         g.C = d->workspace;
         g.slab_stride = (long)d->M * d->N;
-    }
-    {
-        static int env_stagger = -1;
-        if (env_stagger < 0) {
-            const char* e = getenv("APTAI_GEMM_STAGGER");
-            env_stagger = e ? atoi(e) : 0;
-        }
-        g.stagger = (g.flags & (APTAI_EPI_GELU | APTAI_EPI_DGELU)) ? env_stagger : 0;
     }
     return APTAI_OK;
 }
