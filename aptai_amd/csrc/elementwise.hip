@@ -62,39 +62,70 @@ __global__ void conv_weight_kernel(const float* __restrict__ src, bf16_t* __rest
 }
 
 // ---- weight-norm (dim=2) of the positional conv: norm[kk] = ||v[:, :, kk]||_2   (HF:340-356)
-__global__ void posconv_norm_kernel(const float* __restrict__ v, float* __restrict__ norm, long rows /*H*Cg*/, int Kw) {
+// Two deterministic stages over coalesced reads: block b sums its contiguous slice of v with thread t owning tap t % Kw
+// (blockDim % Kw == 0 and slice % blockDim == 0, so a thread's tap never changes), then Kw threads add the block partials.
+constexpr int PCN_BLOCKS = 64;
+__global__ __launch_bounds__(256) void posconv_norm_partial_kernel(const float* __restrict__ v, float* __restrict__ partial,
+                                                                   long n, int Kw) {
     __shared__ float red[256];
-    const int kk = blockIdx.x;
-    float s = 0.f;
-    for (long r = threadIdx.x; r < rows; r += blockDim.x) {
-        const float x = v[r * Kw + kk];
-        s += x * x;
+    const long per = ((n + PCN_BLOCKS - 1) / PCN_BLOCKS + 255) / 256 * 256;
+    const long i0 = (long)blockIdx.x * per;
+    long i1 = i0 + per;
+    i1 = i1 < n ? i1 : n;
+    float s8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s8[u] = 0.f;
+    long i = i0 + threadIdx.x;
+    for (; i + 7 * 256 < i1; i += 8 * 256) {            // 8 independent loads in flight per thread
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = v[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] = fmaf(x[u], x[u], s8[u]);
     }
+    for (; i < i1; i += 256) {
+        const float x = v[i];
+        s8[0] = fmaf(x, x, s8[0]);
+    }
+    const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
+    if ((int)threadIdx.x < Kw) {
+        float t = 0.f;
+        for (int j = threadIdx.x; j < 256; j += Kw) t += red[j];
+        partial[(long)blockIdx.x * Kw + threadIdx.x] = t;
     }
-    if (threadIdx.x == 0) norm[kk] = sqrtf(red[0]);
+}
+__global__ void posconv_norm_final_kernel(const float* __restrict__ partial, float* __restrict__ norm, int Kw) {
+    const int kk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kk >= Kw) return;
+    float s = 0.f;
+    for (int b = 0; b < PCN_BLOCKS; ++b) s += partial[(long)b * Kw + kk];
+    norm[kk] = sqrtf(s);
 }
 
 // w = g*v/norm ->  fwd layout  Wf[grp][n][kk*Cg + c]            = w[grp*Cg+n][c][kk]
 //                  dgrad layout Wd[grp][c][kk'*Cg + n], kk'=Kw-1-kk (flipped taps, in/out swapped)
-__global__ void posconv_weight_kernel(const float* __restrict__ v, const float* __restrict__ gain,
-                                      const float* __restrict__ norm, bf16_t* __restrict__ wf, bf16_t* __restrict__ wd,
-                                      int H, int Cg, int Kw) {
-    const long n = (long)H * Cg * Kw;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int kk = (int)(i % Kw);
-        const int c = (int)((i / Kw) % Cg);
-        const int o = (int)(i / ((long)Kw * Cg));
-        const int grp = o / Cg, nn = o % Cg;
-        const bf16_t w = f2bf(v[i] * gain[kk] / norm[kk]);
-        const long K = (long)Kw * Cg;
-        wf[((long)grp * Cg + nn) * K + (long)kk * Cg + c] = w;
-        if (wd) wd[((long)grp * Cg + c) * K + (long)(Kw - 1 - kk) * Cg + nn] = w;
+// One block per OUTPUT row (H rows of Wf, then H rows of Wd): the Cg x Kw source slab is read in 512-byte runs, transposed
+// through LDS and written as one contiguous bf16 row (both sides coalesced; element-wise scatter took 47 us).
+__global__ __launch_bounds__(256) void posconv_weight_kernel(const float* __restrict__ v, const float* __restrict__ gain,
+                                                             const float* __restrict__ norm, bf16_t* __restrict__ wf,
+                                                             bf16_t* __restrict__ wd, int H, int Cg, int Kw) {
+    extern __shared__ float slab[];                    // [Cg][Kw + 1]
+    const bool dgrad = (int)blockIdx.x >= H;
+    const int row = dgrad ? blockIdx.x - H : blockIdx.x;
+    const int grp = row / Cg, r = row % Cg;            // fwd: r = out channel n; dgrad: r = in channel c
+    const int n = Cg * Kw;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int a = i / Kw, kk = i % Kw;             // fwd: a = c (source row o = row);  dgrad: a = n (source o = grp*Cg + a, c = r)
+        const long src = dgrad ? (((long)(grp * Cg + a) * Cg + r) * Kw + kk) : ((long)row * n + i);
+        slab[a * (Kw + 1) + kk] = v[src] * gain[kk] / norm[kk];
+    }
+    __syncthreads();
+    bf16_t* out = (dgrad ? wd : wf) + (long)row * n;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const int kk = j / Cg, a = j % Cg;             // output index kk*Cg + a
+        out[j] = f2bf(slab[a * (Kw + 1) + (dgrad ? Kw - 1 - kk : kk)]);
     }
 }
 
@@ -323,9 +354,17 @@ extern "C" int aptai_posconv_weight(const float* v, const float* gain, float* no
     APTAI_REQUIRE(v && gain && norm_ws && w_fwd, "aptai_posconv_weight: null pointer");
     APTAI_REQUIRE(groups > 0 && H % groups == 0 && (H / groups) % 8 == 0, "aptai_posconv_weight: H=%ld groups=%ld", (long)H, (long)groups);
     const int Cg = (int)(H / groups);
-    APTAI_LAUNCH(posconv_norm_kernel, dim3((unsigned)Kw), dim3(256), 0, (hipStream_t)stream, v, norm_ws, (long)H * Cg, (int)Kw);
-    APTAI_CHECK_LAUNCH("posconv_norm_kernel");
-    APTAI_LAUNCH(posconv_weight_kernel, dim3(grid_for(H * Cg * Kw)), dim3(256), 0, (hipStream_t)stream, v, gain,
+    APTAI_REQUIRE(Kw > 0 && 256 % Kw == 0, "aptai_posconv_weight: Kw=%ld must divide 256", (long)Kw);
+    const long nel = (long)H * Cg * Kw;
+    float* partial = norm_ws + Kw;                      // [64][Kw] scratch behind the result
+    APTAI_LAUNCH(posconv_norm_partial_kernel, dim3(PCN_BLOCKS), dim3(256), 0, (hipStream_t)stream, v, partial, nel, (int)Kw);
+    APTAI_CHECK_LAUNCH("posconv_norm_partial_kernel");
+    APTAI_LAUNCH(posconv_norm_final_kernel, dim3((unsigned)ceil_div(Kw, 128)), dim3(128), 0, (hipStream_t)stream,
+                 (const float*)partial, norm_ws, (int)Kw);
+    APTAI_CHECK_LAUNCH("posconv_norm_final_kernel");
+    const size_t slab_bytes = (size_t)Cg * (Kw + 1) * 4;
+    APTAI_REQUIRE(slab_bytes <= 64 * 1024, "aptai_posconv_weight: Cg*Kw slab of %ld bytes exceeds the LDS budget", (long)slab_bytes);
+    APTAI_LAUNCH(posconv_weight_kernel, dim3((unsigned)(w_dgrad ? 2 * H : H)), dim3(256), slab_bytes, (hipStream_t)stream, v, gain,
                        (const float*)norm_ws, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, (int)H, Cg, (int)Kw);
     APTAI_CHECK_LAUNCH("posconv_weight_kernel");
     return APTAI_OK;

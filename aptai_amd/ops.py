@@ -289,10 +289,11 @@ def conv_weight_bf16(w: torch.Tensor) -> torch.Tensor:
 def posconv_weight(v, gain, groups, want_dgrad=True):
     _dev(v, gain)
     H, Cg, Kw = v.shape
-    norm = torch.empty(Kw, device=v.device, dtype=torch.float32)
+    norm_ws = torch.empty(65 * Kw, device=v.device, dtype=torch.float32)      # [Kw] result + [64][Kw] reduction scratch
+    norm = norm_ws[:Kw]
     wf = torch.empty((groups, Cg, Kw * Cg), device=v.device, dtype=torch.bfloat16)
     wd = torch.empty_like(wf) if want_dgrad else None
-    _lib.call("aptai_posconv_weight", v.data_ptr(), gain.data_ptr(), norm.data_ptr(), wf.data_ptr(), _ptr(wd), H, groups, Kw,
+    _lib.call("aptai_posconv_weight", v.data_ptr(), gain.data_ptr(), norm_ws.data_ptr(), wf.data_ptr(), _ptr(wd), H, groups, Kw,
               _stream())
     return wf, wd, norm
 
