@@ -53,6 +53,73 @@ struct GemmArgs {
 
 __device__ __forceinline__ int km_swz(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
 
+// gelu(x) and gelu'(x) together (shared sigmoid): forward epilogues that save the activation derivative for the backward
+__device__ __forceinline__ void gelu_fast_both(float x, float& y, float& dy) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -7.0f, 7.0f);
+    const float x2 = xc * xc;
+    const float s = gelu_sig(xc, x2);
+    float q = fmaf(5.0f * APTAI_GELU_A5, x2, 3.0f * APTAI_GELU_A3);
+    q = fmaf(q, x2, APTAI_GELU_A1);
+    y = x * s;
+    dy = fmaf(fmaf(-s, s, s), xc * q, s);
+}
+
+// Everything behind alpha/bias for 8 consecutive columns (n..n+7) of output row m, bf16-output kernels: optional copy of
+// the pre-activation (or, with EPI_PRE_DGELU, of dropmask * gelu'(pre-activation): the factor the backward multiplies by,
+// so the dgrad epilogue is ONE multiply per element instead of a dropout hash and a gelu'), GELU, dropout, x gelu'(aux) or
+// x aux, + residual, packed 16-byte store.
+__device__ __forceinline__ void epilogue_chunk(float (&v)[8], const GemmArgs& g, const int flags, const long m, const int n,
+                                               const u32x4 auxq, const u32x4 resq, const uint32_t sd0, const uint32_t sd1) {
+    const bool pre_dgelu = (flags & APTAI_EPI_PRE_DGELU) != 0;
+    float d[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = 1.0f;
+    if (g.out_pre && !pre_dgelu)
+        *(u32x4*)(g.out_pre + m * g.ldc + n) =
+            (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    if (flags & APTAI_EPI_GELU) {
+        if (pre_dgelu) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) gelu_fast_both(v[r], v[r], d[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
+        }
+    }
+    if (flags & APTAI_EPI_DROPOUT) {
+        const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            const uint32_t hsh = drop_hash_pair(e + r, sd0, sd1);
+            const float k0 = (hsh & 0xffffu) >= g.thr16 ? g.dscale : 0.f, k1 = (hsh >> 16) >= g.thr16 ? g.dscale : 0.f;
+            v[r] *= k0;
+            v[r + 1] *= k1;
+            d[r] *= k0;
+            d[r + 1] *= k1;
+        }
+    }
+    if (g.out_pre && pre_dgelu)
+        *(u32x4*)(g.out_pre + m * g.ldc + n) =
+            (u32x4){pack2bf(d[0], d[1]), pack2bf(d[2], d[3]), pack2bf(d[4], d[5]), pack2bf(d[6], d[7])};
+    if (flags & APTAI_EPI_DGELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[2 * r] *= gelu_fast_grad(lo_bf(auxq[r]));
+            v[2 * r + 1] *= gelu_fast_grad(hi_bf(auxq[r]));
+        }
+    }
+    if (flags & APTAI_EPI_MUL_AUX) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[2 * r] *= lo_bf(auxq[r]); v[2 * r + 1] *= hi_bf(auxq[r]); }
+    }
+    if (flags & APTAI_EPI_RESIDUAL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[2 * r] += lo_bf(resq[r]); v[2 * r + 1] += hi_bf(resq[r]); }
+    }
+    *(u32x4*)((bf16_t*)g.C + m * g.ldc + n) =
+        (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+}
+
 // ---- global -> LDS staging of one operand tile (1024 x 16-B chunks, 4 per thread)
 template <bool KM>
 __device__ __forceinline__ void stage_operand(const bf16_t* __restrict__ base, long ld, int row0, int rows_total,
@@ -217,7 +284,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
             resv[pass] = (u32x4){0u, 0u, 0u, 0u};
             auxv[pass] = (u32x4){0u, 0u, 0u, 0u};
             if (ok && (flags & APTAI_EPI_RESIDUAL)) resv[pass] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
-            if (ok && (flags & APTAI_EPI_DGELU)) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+            if (ok && (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX))) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
         }
     }
     __syncthreads();                                   // every wave is done reading the staging buffers
@@ -263,37 +330,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
             *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
             continue;
         }
-        if (g.out_pre)
-            *(u32x4*)(g.out_pre + (long)m * g.ldc + n) =
-                (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        if (flags & APTAI_EPI_GELU) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
-        }
-        if (flags & APTAI_EPI_DROPOUT) {
-            const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
-#pragma unroll
-            for (int r = 0; r < 8; r += 2) {
-                const uint32_t hsh = drop_hash_pair(e + r, sd0, sd1);
-                v[r] = (hsh & 0xffffu) >= g.thr16 ? v[r] * g.dscale : 0.f;
-                v[r + 1] = (hsh >> 16) >= g.thr16 ? v[r + 1] * g.dscale : 0.f;
-            }
-        }
-        if (flags & APTAI_EPI_DGELU) {
-            const u32x4 a = auxv[pass];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[2 * r] *= gelu_fast_grad(lo_bf(a[r]));
-                v[2 * r + 1] *= gelu_fast_grad(hi_bf(a[r]));
-            }
-        }
-        if (flags & APTAI_EPI_RESIDUAL) {
-            const u32x4 a = resv[pass];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[2 * r] += lo_bf(a[r]); v[2 * r + 1] += hi_bf(a[r]); }
-        }
-        *(u32x4*)((bf16_t*)g.C + (long)m * g.ldc + n) =
-            (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        epilogue_chunk(v, g, flags, (long)m, n, auxv[pass], resv[pass], sd0, sd1);
     }
 }
 
@@ -575,39 +612,12 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
                 *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                 continue;
             }
-            if (g.out_pre)
-                *(u32x4*)(g.out_pre + (long)m * g.ldc + n) =
-                    (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-            if (flags & APTAI_EPI_GELU) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
-            }
-            if (flags & APTAI_EPI_DROPOUT) {
-                uint32_t sd0 = g.seed0, sd1 = g.seed1;
-                apply_salt(g.salt, sd0, sd1);
-                const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
-#pragma unroll
-                for (int r = 0; r < 8; r += 2) {
-                    const uint32_t hsh = drop_hash_pair(e + r, sd0, sd1);
-                    v[r] = (hsh & 0xffffu) >= g.thr16 ? v[r] * g.dscale : 0.f;
-                    v[r + 1] = (hsh >> 16) >= g.thr16 ? v[r + 1] * g.dscale : 0.f;
-                }
-            }
-            if (flags & APTAI_EPI_DGELU) {
-                const u32x4 a = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[2 * r] *= gelu_fast_grad(lo_bf(a[r]));
-                    v[2 * r + 1] *= gelu_fast_grad(hi_bf(a[r]));
-                }
-            }
-            if (flags & APTAI_EPI_RESIDUAL) {
-                const u32x4 a = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[2 * r] += lo_bf(a[r]); v[2 * r + 1] += hi_bf(a[r]); }
-            }
-            *(u32x4*)((bf16_t*)g.C + (long)m * g.ldc + n) =
-                (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            u32x4 auxq = {0u, 0u, 0u, 0u}, resq = {0u, 0u, 0u, 0u};
+            if (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) auxq = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+            if (flags & APTAI_EPI_RESIDUAL) resq = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+            uint32_t sd0 = g.seed0, sd1 = g.seed1;
+            if (flags & APTAI_EPI_DROPOUT) apply_salt(g.salt, sd0, sd1);
+            epilogue_chunk(v, g, flags, (long)m, n, auxq, resq, sd0, sd1);
         }
         __syncthreads();
     }
@@ -817,7 +827,7 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
         resv[pass] = (u32x4){0u, 0u, 0u, 0u};
         auxv[pass] = (u32x4){0u, 0u, 0u, 0u};
     }
-    if (!OUT_F32 && (flags & (APTAI_EPI_RESIDUAL | APTAI_EPI_DGELU))) {     // uniform; addresses clamped, no per-lane branches
+    if (!OUT_F32 && (flags & (APTAI_EPI_RESIDUAL | APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX))) {     // uniform; addresses clamped, no per-lane branches
 #pragma unroll
         for (int pass = 0; pass < 6; ++pass) {
             const int c = pass * T3_THREADS + tid, ml = c / 24, cl = (c - ml * 24) * 8;
@@ -825,7 +835,7 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
             m = m < g.M ? m : g.M - 1;
             n = n <= g.N - 8 ? n : g.N - 8;
             if (flags & APTAI_EPI_RESIDUAL) resv[pass] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
-            if (flags & APTAI_EPI_DGELU) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+            if (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
         }
     }
 #pragma unroll
@@ -863,37 +873,7 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
             *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
             continue;
         }
-        if (g.out_pre)
-            *(u32x4*)(g.out_pre + (long)m * g.ldc + n) =
-                (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        if (flags & APTAI_EPI_GELU) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
-        }
-        if (flags & APTAI_EPI_DROPOUT) {
-            const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
-#pragma unroll
-            for (int r = 0; r < 8; r += 2) {
-                const uint32_t hsh = drop_hash_pair(e + r, sd0, sd1);
-                v[r] = (hsh & 0xffffu) >= g.thr16 ? v[r] * g.dscale : 0.f;
-                v[r + 1] = (hsh >> 16) >= g.thr16 ? v[r + 1] * g.dscale : 0.f;
-            }
-        }
-        if (flags & APTAI_EPI_DGELU) {
-            const u32x4 a = auxv[pass];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[2 * r] *= gelu_fast_grad(lo_bf(a[r]));
-                v[2 * r + 1] *= gelu_fast_grad(hi_bf(a[r]));
-            }
-        }
-        if (flags & APTAI_EPI_RESIDUAL) {
-            const u32x4 a = resv[pass];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[2 * r] += lo_bf(a[r]); v[2 * r + 1] += hi_bf(a[r]); }
-        }
-        *(u32x4*)((bf16_t*)g.C + (long)m * g.ldc + n) =
-            (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        epilogue_chunk(v, g, flags, (long)m, n, auxv[pass], resv[pass], sd0, sd1);
         __builtin_amdgcn_sched_barrier(0);             // keep the passes apart: interleaving all six spills
     }
 }
@@ -934,7 +914,8 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     if (d->b_kmajor) APTAI_REQUIRE(d->N >= 8, "aptai_gemm_bf16: K-major B needs N >= 8");
     if (d->flags & APTAI_EPI_BIAS) APTAI_REQUIRE(d->bias != nullptr, "aptai_gemm_bf16: EPI_BIAS without bias");
     if (d->flags & APTAI_EPI_RESIDUAL) APTAI_REQUIRE(d->residual != nullptr, "aptai_gemm_bf16: EPI_RESIDUAL without residual");
-    if (d->flags & APTAI_EPI_DGELU) APTAI_REQUIRE(d->aux != nullptr, "aptai_gemm_bf16: EPI_DGELU without aux");
+    if (d->flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) APTAI_REQUIRE(d->aux != nullptr, "aptai_gemm_bf16: EPI_DGELU / EPI_MUL_AUX without aux");
+    if (d->flags & APTAI_EPI_PRE_DGELU) APTAI_REQUIRE(d->out_pre != nullptr && (d->flags & APTAI_EPI_GELU), "aptai_gemm_bf16: EPI_PRE_DGELU needs EPI_GELU and out_pre");
 
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)d->A; g.lda = d->lda;

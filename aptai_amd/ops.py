@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_DGELU, EPI_ALPHA = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_DGELU, EPI_ALPHA, EPI_PRE_DGELU, EPI_MUL_AUX = 1, 2, 4, 8, 16, 32, 64, 128
 
 c_void_p, c_i64, c_int, c_float, c_u64 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
                                           ctypes.c_uint64)
@@ -71,9 +71,9 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
                a_kmajor=False, b_kmajor=False, out_f32=False, bias=None, gelu=False, residual=None, out_pre=None,
                dgelu_aux=None, alpha: Optional[float] = None, dropout_p: float = 0.0, seed: int = 0, split_k: int = 1,
                accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None, tile: int = 0,
-               ldaux=None):
+               ldaux=None, pre_dgelu: bool = False, mul_aux=None):
     """Fills one aptai_gemm_desc in place; returns (out, workspace) - the caller keeps them alive across the launch."""
-    _dev(a, b, out, bias, residual, out_pre, dgelu_aux)
+    _dev(a, b, out, bias, residual, out_pre, dgelu_aux, mul_aux)
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     d.A, d.lda = a.data_ptr(), lda if lda is not None else (a.stride(0))
@@ -95,6 +95,11 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
     if dgelu_aux is not None:
         flags |= EPI_DGELU
         d.aux, d.ldaux = dgelu_aux.data_ptr(), dgelu_aux.stride(0)
+    if mul_aux is not None:        # backward partner of pre_dgelu: *= saved dropmask * gelu'(pre-activation)
+        flags |= EPI_MUL_AUX
+        d.aux, d.ldaux = mul_aux.data_ptr(), mul_aux.stride(0)
+    if pre_dgelu:                  # out_pre receives dropmask/(1-p) * gelu'(pre-activation) instead of the pre-activation
+        flags |= EPI_PRE_DGELU
     if alpha is not None:
         flags |= EPI_ALPHA
         d.alpha = alpha

@@ -146,7 +146,9 @@ class _LayerImpl:
             ffn_in, s.m1, s.r1 = ops.layernorm_fwd(s.s1, ln1w, ln1b, cfg.layer_norm_eps, save_stats=need)
             s.x1 = ffn_in
         s.u = torch.empty((M, I), device=x.device, dtype=torch.bfloat16) if need else None
-        s.hact = ops.gemm(ffn_in, w.w1, M, I, H, bias=w.b1, gelu=True, out_pre=s.u, dropout_p=p_a, seed=_seed(self.seed, 3))
+        # with gradients: s.u holds dropmask/(1-p) * gelu'(pre-activation), the factor the dgrad epilogue multiplies by
+        s.hact = ops.gemm(ffn_in, w.w1, M, I, H, bias=w.b1, gelu=True, out_pre=s.u, pre_dgelu=need and _PRE_DGELU, dropout_p=p_a,
+                          seed=_seed(self.seed, 3))
         res2 = s.s1 if pre else ffn_in
         s.s2 = ops.gemm(s.hact, w.w2, M, H, I, bias=w.b2, residual=res2, dropout_p=p_h, seed=_seed(self.seed, 4))
         if pre:
@@ -191,7 +193,10 @@ class _LayerImpl:
         if not grouped:
             dw2, dbias2 = on_side(lambda: (ops.gemm(d_ffn_out, s.hact, H, I, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[3]),
                                            ops.colsum(d_ffn_out, M, H)))
-        du = ops.gemm(d_ffn_out, w.w2, M, I, H, b_kmajor=True, dgelu_aux=s.u, dropout_p=p_a, seed=_seed(self.seed, 3))
+        if _PRE_DGELU:
+            du = ops.gemm(d_ffn_out, w.w2, M, I, H, b_kmajor=True, mul_aux=s.u)
+        else:                                        # APTAI_PRE_DGELU=0: recompute mask and gelu' in the dgrad epilogue (A/B)
+            du = ops.gemm(d_ffn_out, w.w2, M, I, H, b_kmajor=True, dgelu_aux=s.u, dropout_p=p_a, seed=_seed(self.seed, 3))
         if not grouped:
             dw1, dbias1 = on_side(lambda: (ops.gemm(du, ffn_in, I, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[2]),
                                            ops.colsum(du, M, I)))
@@ -238,6 +243,7 @@ class _LayerImpl:
 
 _SIDE_STREAMS = {}
 _GROUPED_WGRAD = os.environ.get("APTAI_GROUPED_WGRAD", "1") != "0"
+_PRE_DGELU = os.environ.get("APTAI_PRE_DGELU", "1") != "0"
 _USE_SIDE_STREAM = os.environ.get("APTAI_SIDE_STREAM", "0") != "0"     # measured neutral on MI355X (A/B 15.95 vs 15.98 ms/step)
 
 

@@ -48,7 +48,9 @@ enum {
     APTAI_EPI_RESIDUAL = 4,  /* += residual[m*ldr+n] (bf16) */
     APTAI_EPI_DROPOUT = 8,   /* counter-based mask from (seed, m*N+n); scaled by 1/(1-p) */
     APTAI_EPI_DGELU = 16,    /* *= gelu'(aux[m*ldaux+n]) — backward of the FFN activation */
-    APTAI_EPI_ALPHA = 32
+    APTAI_EPI_ALPHA = 32,
+    APTAI_EPI_PRE_DGELU = 64, /* with EPI_GELU: out_pre receives dropmask/(1-p) * gelu'(pre-activation) instead of the pre-activation */
+    APTAI_EPI_MUL_AUX = 128   /* *= aux[m*ldaux+n] (bf16): the backward partner of EPI_PRE_DGELU */
 };
 
 typedef struct {
