@@ -120,27 +120,24 @@ __device__ __forceinline__ void epilogue_chunk(float (&v)[8], const GemmArgs& g,
         (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
 }
 
-// ---- global -> LDS staging of one operand tile (1024 x 16-B chunks, 4 per thread)
+// ---- global -> LDS staging of one operand tile (1024 x 16-B chunks, 4 per thread).
+// stage_src: the per-thread source of staging instruction `it` at K offset 0.  The kernel keeps the 8 pointers (4 per operand)
+// in registers and advances them by one K-tile per stage: recomputing `(k0 + krow) * ld` for K-major operands cost two
+// v_mul_lo_u32 + one v_mad_u64_u32 (quarter-rate) per load per K-tile.
 template <bool KM>
-__device__ __forceinline__ void stage_operand(const bf16_t* __restrict__ base, long ld, int row0, int rows_total,
-                                              int k0, char* lds_tile, int tid, int wave_base_tid) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int cid = it * NTHREADS + tid;
-        const bf16_t* src;
-        if (!KM) {
-            const int row = cid >> 3, pc = cid & 7;
-            int grow = row0 + row;
-            grow = grow < rows_total ? grow : rows_total - 1;
-            src = base + (long)grow * ld + k0 + ((pc ^ (row & 7)) << 3);
-        } else {
-            const int krow = cid >> 4, pc = cid & 15;
-            int col = row0 + ((pc ^ km_swz(krow)) << 3);
-            col = col <= rows_total - 8 ? col : rows_total - 8;
-            src = base + (long)(k0 + krow) * ld + col;
-        }
-        char* dst = lds_tile + (it * NTHREADS + wave_base_tid) * 16;   // wave-uniform; HW adds lane*16
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst), 16, 0, 0);
+__device__ __forceinline__ const bf16_t* stage_src(const bf16_t* __restrict__ base, long ld, int row0, int rows_total, int it,
+                                                   int tid) {
+    const int cid = it * NTHREADS + tid;
+    if (!KM) {
+        const int row = cid >> 3, pc = cid & 7;
+        int grow = row0 + row;
+        grow = grow < rows_total ? grow : rows_total - 1;
+        return base + (long)grow * ld + ((pc ^ (row & 7)) << 3);
+    } else {
+        const int krow = cid >> 4, pc = cid & 15;
+        int col = row0 + ((pc ^ km_swz(krow)) << 3);
+        col = col <= rows_total - 8 ? col : rows_total - 8;
+        return base + (long)krow * ld + col;
     }
 }
 
@@ -209,19 +206,33 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
 
     const int wave_base_tid = wave * 64;
     const bool wave_active = (m0 + wm * 64 < g.M) && (n0 + wn * 64 < g.N);
-    if (nk > 0) {
-        stage_operand<A_KM>(g.A, g.lda, m0, g.M, kt_begin * BK, smem, tid, wave_base_tid);
-        stage_operand<B_KM>(g.B, g.ldb, n0, g.N, kt_begin * BK, smem + OPER_BYTES, tid, wave_base_tid);
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+    const long stepA = A_KM ? (long)BK * g.lda : (long)BK, stepB = B_KM ? (long)BK * g.ldb : (long)BK;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        pa[it] = stage_src<A_KM>(g.A, g.lda, m0, g.M, it, tid) + kt_begin * stepA;
+        pb[it] = stage_src<B_KM>(g.B, g.ldb, n0, g.N, it, tid) + kt_begin * stepB;
     }
+    auto stage = [&](char* buf) {                     // K-tiles are staged in order: every call advances the sources
+        char* dst = buf + wave_base_tid * 16;          // wave-uniform; the hardware adds lane * 16
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pa[it]), LDS_PTR(dst + it * (NTHREADS * 16)), 16, 0, 0);
+            pa[it] += stepA;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pb[it]), LDS_PTR(dst + OPER_BYTES + it * (NTHREADS * 16)), 16, 0, 0);
+            pb[it] += stepB;
+        }
+    };
+    if (nk > 0) stage(smem);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            char* nxt = smem + (cur ^ 1) * STAGE_BYTES;
-            stage_operand<A_KM>(g.A, g.lda, m0, g.M, (kt_begin + kt + 1) * BK, nxt, tid, wave_base_tid);
-            stage_operand<B_KM>(g.B, g.ldb, n0, g.N, (kt_begin + kt + 1) * BK, nxt + OPER_BYTES, tid, wave_base_tid);
-        }
+        if (kt + 1 < nk) stage(smem + (cur ^ 1) * STAGE_BYTES);
         const char* sa = smem + cur * STAGE_BYTES;
         const char* sb = sa + OPER_BYTES;
         // a wave whose 64 x 64 quadrant lies wholly outside the problem (grouped positional conv: 48 channels per group;
