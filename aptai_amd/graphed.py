@@ -103,11 +103,15 @@ class GraphedAPTAIStep:
         w._cache.clear()
         w._cache_mode = "build"
         w._layer_plan()                                      # persistent copies + job table exist before capture
+        w._cache_mode = None
+        w._refresh_layer_copies(force=True)                  # copies valid before the first replay whoever refreshes them later
+        w._cache_mode = "build"
         torch.cuda.synchronize()
         self.g_prep = mk()
         with torch.cuda.graph(self.g_prep, pool=pool):
             w._conv_weights()
-            w._refresh_layer_copies(force=True)
+            if not getattr(self.opt, "publishes_copies", False):     # else the optimiser kernel refreshes the copies itself
+                w._refresh_layer_copies(force=True)
             self.lw = [w._layer_weights(i, g.M) for i in range(L)]
             fp, pc = w.feature_projection, w.encoder.pos_conv_embed.conv
             w._cached(("proj",), [fp.projection.weight], lambda: ops.cast_bf16(fp.projection.weight))

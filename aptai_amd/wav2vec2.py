@@ -568,12 +568,15 @@ class Wav2Vec2Model(nn.Module):
         params = [p for i in range(len(self.encoder.layers)) for p in self._layer_params(i)]
         ver = self._versions(params)
         trainable = self.training and any(p.requires_grad for p in params)
-        # an eval forward right after training must not trust the versions either (the last optimiser step is unseen)
-        if force or mode == "build" or trainable or plan.version != ver or getattr(plan, "after_training", False):
+        # an eval forward right after training must not trust the versions either (the last optimiser step is unseen) -
+        # unless the optimiser itself writes the copies (aptai_amd.optim.Adam.publish_to sets plan.optimizer_synced)
+        synced = getattr(plan, "optimizer_synced", False)
+        stale_by_training = (trainable or getattr(plan, "after_training", False)) and not synced
+        if force or mode == "build" or stale_by_training or plan.version != ver:
             with torch.no_grad():
                 plan.run()
             plan.version = ver
-            plan.after_training = bool(trainable)
+            plan.after_training = bool(trainable) and not synced
 
     def _layer_weights(self, i: int, M: int):
         e = self._layer_plan().entries[i]

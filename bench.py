@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-regularisers", action="store_true", help="dropout/LayerDrop/SpecAugment off (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of aptai_amd.optim.Adam")
     ap.add_argument("--eager", action="store_true", help="drive the step through autograd (the drop-in loop) instead of hipGraphs")
     return ap.parse_args()
 
@@ -196,7 +197,11 @@ def main():
     model.wav2vec2.base_seed += rank
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, fused=True)
+    if args.torch_adam:
+        opt = torch.optim.Adam(params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, fused=True)
+    else:                                                    # same update rule as one multi-tensor HIP kernel (csrc/optim.hip)
+        from aptai_amd.optim import Adam
+        opt = Adam(params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8).publish_to(model)
     reducer = GradBucketReducer(params, bucket_mb=48.0, comm_dtype=torch.bfloat16) if world > 1 else None
     batch = synth_batch(cfg, B, S, args.n_tv, rank, device)
 
@@ -276,7 +281,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": world * B, "clip_seconds": args.seconds,
                        "frames_per_clip": int(S // 320 - (1 if S % 320 < 80 else 0)) if False else None,
                        "parallelism": f"dp{world}", "regularisers": "off" if args.no_regularisers else "HF defaults",
-                       "optimizer": "Adam (torch fused, fp32 state)",
+                       "optimizer": "Adam, fp32 state (torch fused)" if args.torch_adam else "Adam, fp32 state (aptai_adam_multi, refreshes the bf16 weight copies)",
                        "execution": "eager autograd loop" if args.eager else "hipGraph segments (aptai_amd.graphed)"},
             "loss": round(loss, 5),
             "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM, NT layout (gemm_kernel / gemm192_kernel / gemm256_kernel <false,false,false>): every launch of the step",

@@ -121,6 +121,13 @@ int aptai_cast_f32_to_bf16(const float* src, void* dst, int64_t rows, int64_t co
 /* Many casts in one launch.  table_dev: device int64 [njobs][4] = {src fp32 ptr, dst ptr, n, kind}; n % 8 == 0, both
  * pointers 32-/16-byte aligned; kind 0 = fp32 -> bf16, 1 = fp32 -> fp32 copy (packs q/k/v biases); max_n = largest n. */
 int aptai_cast_multi(const int64_t* table_dev, int64_t njobs, int64_t max_n, void* stream);
+/* torch.optim.Adam step (train/train_aptai.py:350-356, 443) for many tensors in one launch.  table_dev: device int64
+ * [njobs][6] = {param, exp_avg, exp_avg_sq, copy_dst or 0, n, copy_kind (0 = bf16, 1 = fp32)} (static across steps);
+ * dyn_dev: device int64 [njobs][2] = {grad or 0 (no gradient this step: the job is skipped), step count of this update >= 1}
+ * (rewritten every step).  All tensors fp32 with n elements; copy_dst receives the updated parameter (the compute copy the
+ * forward reads).  Bias corrections 1 - beta^step are evaluated per job in double, as torch does on the host. */
+int aptai_adam_multi(const int64_t* table_dev, const int64_t* dyn_dev, int64_t njobs, int64_t max_n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, void* stream);
 /* nn.Conv1d weight [N][C][Kw] (HF:260-266) -> [N][Kw*C] bf16, K index = kw*C + c (channels-last frames) */
 int aptai_conv_weight_to_bf16(const float* src, void* dst, int64_t N, int64_t C, int64_t Kw, void* stream);
 /* positional conv (HF:329-356): weight_norm(dim=2) w = g*v/||v||_(0,1) ; v [H][H/groups][Kw], gain [Kw];
