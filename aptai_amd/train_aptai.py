@@ -52,9 +52,11 @@ def load_model_optimizer(args_cfg):
     pretrain_cfg = args_cfg.pretrain_cfg
     model = APTAI(device=args_cfg.device, vocab=args_cfg.vocab, huggingface_model_id=args_cfg.huggingface_model_id,
                   pretrain_cfg=pretrain_cfg, cache_dir=getattr(args_cfg, "cache_dir", None)).to(args_cfg.device)
-    optimizer = torch.optim.Adam(model.parameters(), lr=args_cfg.learning_rate, betas=(args_cfg.adam_beta1, args_cfg.adam_beta2),
-                                 eps=args_cfg.adam_epsilon, weight_decay=args_cfg.adam_weight_decay,
-                                 **({"fused": True} if torch.device(args_cfg.device).type == "cuda" else {}))
+    # torch.optim.Adam's update rule as one multi-tensor HIP kernel (aptai_amd.optim.Adam; same constructor, param_groups and
+    # state keys).  `torch.optim.Adam(model.parameters(), ...)` works unchanged on the same parameters.
+    from .optim import Adam
+    optimizer = Adam(model.parameters(), lr=args_cfg.learning_rate, betas=(args_cfg.adam_beta1, args_cfg.adam_beta2),
+                     eps=args_cfg.adam_epsilon, weight_decay=args_cfg.adam_weight_decay).publish_to(model)
     lr_scheduler = torch.optim.lr_scheduler.LambdaLR(
         optimizer=optimizer, lr_lambda=hostlogic.get_lr_schedule(args_cfg.num_warmup_epochs, args_cfg.num_static_epochs, args_cfg.lr_decay))
     return model, optimizer, lr_scheduler
