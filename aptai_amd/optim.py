@@ -43,15 +43,16 @@ class Adam(torch.optim.Optimizer):
     def _group_tables(self, gi: int, group):
         """Static job table of a parameter group (all its parameters, whether or not they get a gradient this step) and a
         small ring of pinned host buffers for the per-step column {grad pointer, step count}."""
-        params = group["params"]
-        key = tuple(p.data_ptr() for p in params)
+        key = tuple(p.data_ptr() for p in group["params"])
         cached = self._tables.get(gi)
         if cached is not None and cached["key"] == key:
             return cached
+        # parameters the kernel cannot update (e.g. the float64 low-pass taps, which are never trained) stay out of the table;
+        # step() raises if one of them ever shows up with a gradient
+        params = [p for p in group["params"] if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()]
+        others = [p for p in group["params"] if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous())]
         rows = []
         for p in params:
-            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-                raise _lib.AptaiHipError("aptai_amd.optim.Adam needs contiguous fp32 parameters on the MI355X")
             st = self.state[p]
             if len(st) == 0:
                 st["step"] = 0                        # python int here; state_dict() emits torch's tensor form
@@ -64,7 +65,7 @@ class Adam(torch.optim.Optimizer):
         cached = dict(key=key, table=torch.tensor(rows, dtype=torch.int64).to(dev), max_n=max(r[4] for r in rows),
                       dyn_dev=torch.zeros((len(params), 2), dtype=torch.int64, device=dev),
                       ring=[torch.zeros((len(params), 2), dtype=torch.int64).pin_memory() for _ in range(4)],
-                      events=[None] * 4, turn=0, states=[self.state[p] for p in params])
+                      events=[None] * 4, turn=0, states=[self.state[p] for p in params], params=params, others=others)
         self._tables[gi] = cached
         return cached
 
@@ -76,12 +77,14 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         stream = torch.cuda.current_stream()
         for gi, group in enumerate(self.param_groups):
-            params = group["params"]
-            if not params or not params[0].is_cuda:
-                if any(p.grad is not None for p in params):
+            if not any(p.is_cuda for p in group["params"]):
+                if any(p.grad is not None for p in group["params"]):
                     raise _lib.AptaiHipError("aptai_amd.optim.Adam needs parameters on the MI355X (no CPU fallback)")
                 continue
             t = self._group_tables(gi, group)
+            params = t["params"]
+            if any(p.grad is not None for p in t["others"]):
+                raise _lib.AptaiHipError("aptai_amd.optim.Adam updates contiguous fp32 parameters on the MI355X only")
             slot = t["turn"]
             t["turn"] = (slot + 1) % len(t["ring"])
             if t["events"][slot] is not None:
