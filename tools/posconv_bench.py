@@ -1,0 +1,19 @@
+"""Positional-conv GEMM (grouped Conv1d k=128, 16 groups of 48 channels) as the batched overlapping-row GEMM the model issues."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from aptai_amd import ops
+from tools.gemm_bench import bench
+B, Tp, H, G, Kw = 16, 512, 768, 16, 128
+Cg, pad = H // G, Kw // 2
+rows_p, K = Tp + 2 * pad, Kw * Cg
+g = torch.Generator(device="cuda").manual_seed(0)
+xg = torch.randn(G * B * rows_p * Cg + Cg * 8, device="cuda", generator=g).to(torch.bfloat16)
+wf = (torch.randn(G, Cg, K, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+out = torch.empty(B * Tp, H, device="cuda", dtype=torch.bfloat16)
+bias = torch.randn(H, device="cuda")
+batch = dict(outer=B, inner=G, a=(rows_p * Cg, B * rows_p * Cg), b=(0, Cg * K), c=(Tp * H, Cg), bias=(0, Cg), res=(Tp * H, Cg), aux=(Tp * H, Cg))
+fl = 2.0 * B * Tp * H * K
+for tile in (128, 64):
+    t = bench(lambda: ops.gemm(xg, wf, Tp, Cg, K, lda=Cg, ldb=K, out=out, ldc=H, bias=bias, gelu=True, batch=batch, tile=tile), iters=20)
+    print(f"tile={tile}: {t:.1f} us  {fl/t/1e6:.0f} TF useful")
