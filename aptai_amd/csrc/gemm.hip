@@ -169,8 +169,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-// one 128 x 128 output tile: `bid` is the (already remapped) tile index of problem g, `batch` < 0 = not batched
-template <bool A_KM, bool B_KM, bool OUT_F32>
+// one BM_T x 128 output tile: `bid` is the (already remapped) tile index of problem g, `batch` < 0 = not batched.
+// BM_T = 128: wave tile 64 x 64, 2 blocks per CU.  BM_T = 64 (K-contiguous A only): wave tile 32 x 64, 24 KiB stages, 3 blocks
+// per CU = 768 slots - for [8192] x 768 outputs, whose 384 big tiles fill only 0.75 of one round of 512 slots while their 768
+// half tiles are exactly one round of 768.
+template <bool A_KM, bool B_KM, bool OUT_F32, int BM_T = 128>
 __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const int batch, const int split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -179,7 +182,14 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    constexpr int NI = BM_T / 32;                       // 16-row MFMA tiles per wave
+    constexpr int WM = BM_T / 2;                        // wave tile height
+    constexpr int NA_IT = BM_T / 32;                    // staging instructions per thread for the A tile
+    constexpr int A_BYTES_T = BM_T * BK * 2;
+    constexpr int STAGE_T = A_BYTES_T + BN * BK * 2;
+    constexpr int NPASS = BM_T / 16;                    // epilogue passes of 16 rows
+    static_assert(BM_T == 128 || (BM_T == 64 && !A_KM), "64-row tiles are built for K-contiguous A only");
+    const int m0 = tile_m * BM_T, n0 = tile_n * BN;
 
     if (batch >= 0) {
         const int bo = batch / g.nb_inner, bi = batch % g.nb_inner;
@@ -198,32 +208,31 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     kt_end = kt_end < total_kt ? kt_end : total_kt;
     const int nk = kt_end - kt_begin;
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int wave_base_tid = wave * 64;
-    const bool wave_active = (m0 + wm * 64 < g.M) && (n0 + wn * 64 < g.N);
-    const bf16_t* pa[4];
+    const bool wave_active = (m0 + wm * WM < g.M) && (n0 + wn * 64 < g.N);
+    const bf16_t* pa[NA_IT];
     const bf16_t* pb[4];
     const long stepA = A_KM ? (long)BK * g.lda : (long)BK, stepB = B_KM ? (long)BK * g.ldb : (long)BK;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        pa[it] = stage_src<A_KM>(g.A, g.lda, m0, g.M, it, tid) + kt_begin * stepA;
-        pb[it] = stage_src<B_KM>(g.B, g.ldb, n0, g.N, it, tid) + kt_begin * stepB;
-    }
+    for (int it = 0; it < NA_IT; ++it) pa[it] = stage_src<A_KM>(g.A, g.lda, m0, g.M, it, tid) + kt_begin * stepA;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) pb[it] = stage_src<B_KM>(g.B, g.ldb, n0, g.N, it, tid) + kt_begin * stepB;
     auto stage = [&](char* buf) {                     // K-tiles are staged in order: every call advances the sources
         char* dst = buf + wave_base_tid * 16;          // wave-uniform; the hardware adds lane * 16
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < NA_IT; ++it) {
             __builtin_amdgcn_global_load_lds(GLB_PTR(pa[it]), LDS_PTR(dst + it * (NTHREADS * 16)), 16, 0, 0);
             pa[it] += stepA;
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(pb[it]), LDS_PTR(dst + OPER_BYTES + it * (NTHREADS * 16)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pb[it]), LDS_PTR(dst + A_BYTES_T + it * (NTHREADS * 16)), 16, 0, 0);
             pb[it] += stepB;
         }
     };
@@ -232,9 +241,9 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(smem + (cur ^ 1) * STAGE_BYTES);
-        const char* sa = smem + cur * STAGE_BYTES;
-        const char* sb = sa + OPER_BYTES;
+        if (kt + 1 < nk) stage(smem + (cur ^ 1) * STAGE_T);
+        const char* sa = smem + cur * STAGE_T;
+        const char* sb = sa + A_BYTES_T;
         // a wave whose 64 x 64 quadrant lies wholly outside the problem (grouped positional conv: 48 channels per group;
         // bias-gradient problems: M = 8; heads: N = 64) stages and synchronises but issues no LDS reads and no MFMAs
         if (wave_active) {
@@ -243,32 +252,32 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
                 // keeps the compiler from sinking them next to their uses): one exposed LDS latency per K-tile instead of
                 // one per fragment group (+9 % at K = 3072).  With transposing reads (K-major operands) the same hoist
                 // measured 4-7 % slower, so those variants keep the compiler's order.
-                bf16x8 af[2][4], bfr[2][4];
+                bf16x8 af[2][NI], bfr[2][4];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) bfr[ks][j] = read_frag<B_KM>(sb, wn * 64 + j * 16, ks, lane);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<A_KM>(sa, wm * 64 + i * 16, ks, lane);
+                    for (int i = 0; i < NI; ++i) af[ks][i] = read_frag<A_KM>(sa, wm * WM + i * 16, ks, lane);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 af[4], bfr[4];
+                    bf16x8 af[NI], bfr[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = read_frag<A_KM>(sa, wm * 64 + i * 16, ks, lane);
+                    for (int i = 0; i < NI; ++i) af[i] = read_frag<A_KM>(sa, wm * WM + i * 16, ks, lane);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) bfr[j] = read_frag<B_KM>(sb, wn * 64 + j * 16, ks, lane);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
@@ -286,10 +295,10 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     const int cl = (tid & 15) * 8;                     // column inside the tile, fixed per thread
     const int n = n0 + cl;
     const bool n_ok = n < g.N;
-    u32x4 resv[8], auxv[8];
+    u32x4 resv[NPASS], auxv[NPASS];
     if (!OUT_F32) {
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int m = m0 + pass * 16 + (tid >> 4);
             const bool ok = n_ok && m < g.M;
             resv[pass] = (u32x4){0u, 0u, 0u, 0u};
@@ -302,8 +311,8 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     {
         char* ct = smem;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ml = wm * 64 + i * 16 + (lane & 15);
+        for (int i = 0; i < NI; ++i) {
+            const int ml = wm * WM + i * 16 + (lane & 15);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
@@ -326,7 +335,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     uint32_t sd0 = g.seed0, sd1 = g.seed1;
     if (flags & APTAI_EPI_DROPOUT) apply_salt(g.salt, sd0, sd1);
 #pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
         const int ml = pass * 16 + (tid >> 4);
         const int m = m0 + ml;
         if (m >= g.M || !n_ok) continue;
@@ -349,6 +358,13 @@ template <bool A_KM, bool B_KM, bool OUT_F32>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
     gemm_tile_body<A_KM, B_KM, OUT_F32>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), gridDim.y > 1 ? (int)blockIdx.y : -1,
                                         blockIdx.z);
+}
+
+constexpr int SMEM_M64_BYTES = 2 * (64 + BN) * BK * 2;      // 48 KiB >= the 64 x 128 fp32 epilogue tile (33 KiB): 3 blocks per CU
+template <bool B_KM, bool OUT_F32>
+__global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel_m64(GemmArgs g) {
+    gemm_tile_body<false, B_KM, OUT_F32, 64>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), gridDim.y > 1 ? (int)blockIdx.y : -1,
+                                             blockIdx.z);
 }
 
 // Grouped launch: the tiles of up to MAX_GROUP independent problems of one operand layout in ONE grid.  Made for the four
@@ -382,6 +398,16 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, float* __r
         for (int k = 0; k < nsplit; ++k) s += ((const f32x4*)slabs)[(long)k * slab_stride4 + i];
         ((f32x4*)out)[i] = s;
     }
+}
+
+template <bool B_KM, bool OUT_F32>
+int launch_gemm_m64(GemmArgs g, int nbatch, int nsplit, hipStream_t stream) {
+    auto kern = gemm_kernel_m64<B_KM, OUT_F32>;
+    g.tiles_m = (int)ceil_div(g.M, 64);
+    dim3 grid(g.tiles_m * g.tiles_n, nbatch, nsplit);
+    APTAI_LAUNCH(kern, grid, dim3(NTHREADS), SMEM_M64_BYTES, stream, g);
+    APTAI_CHECK_LAUNCH("gemm_kernel_m64");
+    return APTAI_OK;
 }
 
 template <bool A_KM, bool B_KM, bool OUT_F32>
@@ -1012,8 +1038,22 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         const long t192 = ceil_div(d->M, T3_BM) * ceil_div(d->N, T3_BN) * nbatch * nsplit;
         if (tile == 128 && !d->a_kmajor && !d->b_kmajor && d->M % T3_BM == 0 && d->N % T3_BN == 0 && t192 > 192 && t192 <= 256)
             tile = 192;
+        // dgrad (B K-major) of the same [8192] x 768 outputs: 384 big tiles fill 0.75 of 512 slots; as 768 tiles of 64 x 128
+        // they are one round of 768 slots (3 blocks per CU): 49.1 vs 54.9 us at K = 3072, 38.0 vs 42.9 us at K = 2304, no
+        // gain at K = 768
+        static int m64 = -1;
+        if (m64 < 0) {
+            const char* e = getenv("APTAI_GEMM_M64");             // A/B switch
+            m64 = e ? atoi(e) : 1;
+        }
+        if (m64 && tile == 128 && !d->a_kmajor && d->b_kmajor && d->M % 64 == 0 && t128 > 256 && t128 <= 384 && d->K >= 1536) tile = 64;
     }
+    if (tile == 64 && d->a_kmajor) tile = 128;            // 64-row tiles need a K-contiguous A
     int rc;
+    if (tile == 64) {
+        if (!d->b_kmajor) rc = f32 ? launch_gemm_m64<false, true>(g, nbatch, nsplit, stream) : launch_gemm_m64<false, false>(g, nbatch, nsplit, stream);
+        else rc = f32 ? launch_gemm_m64<true, true>(g, nbatch, nsplit, stream) : launch_gemm_m64<true, false>(g, nbatch, nsplit, stream);
+    } else
     if (tile == 192) {
         if (!d->a_kmajor && !d->b_kmajor) rc = f32 ? launch_gemm192<false, false, true>(g, nbatch, nsplit, stream) : launch_gemm192<false, false, false>(g, nbatch, nsplit, stream);
         else if (!d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm192<false, true, true>(g, nbatch, nsplit, stream) : launch_gemm192<false, true, false>(g, nbatch, nsplit, stream);

@@ -73,7 +73,7 @@ typedef struct {
     int batch_outer, batch_inner;
     int64_t batch_stride_a[2], batch_stride_b[2], batch_stride_c[2], batch_stride_bias[2], batch_stride_res[2],
         batch_stride_aux[2];
-    int tile;                       /* 0 = auto, 128 = 128x128 tile kernel (2 blocks/CU), 192 = 128x192 tile, 3-stage ring
+    int tile;                       /* 0 = auto, 64 = 64x128 tile (3 blocks/CU, K-contiguous A), 128 = 128x128 tile kernel (2 blocks/CU), 192 = 128x192 tile, 3-stage ring
                                        (1 block/CU), 256 = 256x256 deep-pipelined kernel */
 } aptai_gemm_desc;
 
