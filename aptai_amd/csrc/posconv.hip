@@ -1,0 +1,159 @@
+// Positional convolution of the wav2vec2 encoder (HF:326-379: grouped Conv1d, k = 128, 16 groups, "same" padding) as a
+// dedicated MFMA kernel for 48 channels per group (wav2vec2-base).
+//
+// As an implicit GEMM (gemm.hip, lda = Cg < K = 128*Cg) row t of the A operand is the 6144 contiguous elements starting at
+// frame t of the group-major, zero-gapped copy: consecutive rows overlap in all but 48 elements, yet every K-tile re-stages
+// 128 rows x 128 B through the texture path, and 48-channel outputs fill 37.5 % of a 128-wide tile.  Here a block keeps the
+// whole input window of its 128 output frames in LDS ONCE (255 frames x 96 B = 24 KB) and reads MFMA A fragments straight out
+// of it at the Toeplitz row stride: A[t][k] sits at byte 96 t + 2 k whatever k = kw*48 + c is.  Only the weights stream (6 KB
+// per K-tile); all MFMA tiles are real (2 x 3 tiles of 16 x 16 per wave).  A ds_read_b128 lane group {0-3,12-15,20-27} then
+// touches start banks 24 r + 4 q (mod 64) = 16 distinct multiples of 4: conflict-free without any swizzle.
+//
+// The same kernel is the data gradient (flipped-tap weights, input = packed dY one row later) - exactly the two calls the
+// model made through aptai_gemm_bf16.
+#include "common.h"
+
+namespace {
+
+constexpr int CG = 48, KW = 128, FR = 128;              // channels per group, taps, output frames per block
+constexpr int KTOT = KW * CG;                           // 6144
+constexpr int XROWS = FR + KW - 1;                      // 255 input frames
+constexpr int X_BYTES = 6 * 256 * 16;                   // 24 KiB (255 * 96 = 24480 B used)
+constexpr int W_STAGE = 512 * 16;                       // 8 KiB (48 rows x 128 B used)
+
+struct PosconvArgs {
+    const bf16_t* xg; long x_group_stride, x_batch_stride;   // elements: [G][B][rows_p][48]
+    const bf16_t* w;                                           // [G][48][6144]
+    const float* bias;                                         // [H] or null
+    const bf16_t* residual;                                    // [B*Tp][H] or null
+    bf16_t* out;                                               // [B*Tp][H]
+    bf16_t* out_pre;                                           // pre-activation copy or null
+    int Tp, H, gelu;
+};
+
+__global__ __launch_bounds__(256, 3) void posconv_kernel(PosconvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;
+    char* sW = smem + X_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * FR, b = blockIdx.y, grp = blockIdx.z;
+
+    // ---- input window: 1530 x 16 B, contiguous in the packed copy (chunks beyond it re-read the last one into LDS padding)
+    const bf16_t* xsrc = a.xg + (long)grp * a.x_group_stride + (long)b * a.x_batch_stride + (long)t0 * CG;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        int c = it * 256 + tid;
+        c = c < (XROWS * CG * 2) / 16 ? c : (XROWS * CG * 2) / 16 - 1;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(xsrc + (long)c * 8), LDS_PTR(sX + (it * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+    // ---- weight K-tiles: [48][64] bf16, 128-B rows, chunk index XORed with (row & 7); 2 chunks per thread (rows >= 48 clamp)
+    const bf16_t* wg = a.w + (long)grp * CG * KTOT;
+    const bf16_t* pw[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = it * 256 + tid, row = c >> 3, pc = c & 7;
+        const int r = row < CG ? row : CG - 1;
+        pw[it] = wg + (long)r * KTOT + ((pc ^ (row & 7)) << 3);
+    }
+    auto stage_w = [&](char* buf) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pw[it]), LDS_PTR(buf + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            pw[it] += 64;
+        }
+    };
+    stage_w(sW);
+
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment offsets (loop invariant): A row = wave*32 + i*16 + (lane&15), 16-B chunk (lane>>4) of the 32-k slice
+    const int a_off = (wave * 32 + (lane & 15)) * (CG * 2) + (lane >> 4) * 16;
+    int b_off[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = j * 16 + (lane & 15), q = ks * 4 + (lane >> 4);
+            b_off[j][ks] = row * 128 + ((q ^ (row & 7)) << 4);
+        }
+
+    constexpr int NKT = KTOT / 64;                      // 96
+    for (int kt = 0; kt < NKT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = kt & 1;
+        if (kt + 1 < NKT) stage_w(sW + (cur ^ 1) * W_STAGE);
+        const char* sw = sW + cur * W_STAGE;
+        const char* sa = sX + a_off + kt * 128;         // k advances by 64 elements = 128 B per K-tile
+        bf16x8 af[2][2], bfr[2][3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[ks][i] = *(const bf16x8*)(sa + i * (16 * CG * 2) + ks * 64);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bfr[ks][j] = *(const bf16x8*)(sw + b_off[j][ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- epilogue: lane owns 4 consecutive channels of one frame per MFMA tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long row = (long)b * a.Tp + t0 + wave * 32 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = grp * CG + j * 16 + (lane >> 4) * 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (a.bias) {
+                const f32x4 bv = *(const f32x4*)(a.bias + col);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bv[r];
+            }
+            if (a.out_pre) *(u32x2*)(a.out_pre + row * a.H + col) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            if (a.gelu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+            }
+            if (a.residual) {
+                const u32x2 rv = *(const u32x2*)(a.residual + row * a.H + col);
+                v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
+            }
+            *(u32x2*)(a.out + row * a.H + col) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int aptai_posconv_gemm(const void* xg, int64_t first_row, const void* w, const float* bias, const void* residual, void* out,
+                                  void* out_pre, int64_t B, int64_t Tp, int64_t H, int64_t groups, int64_t Kw, int64_t pad, int gelu,
+                                  void* stream) {
+    APTAI_REQUIRE(xg && w && out, "aptai_posconv_gemm: null pointer");
+    APTAI_REQUIRE(groups > 0 && H == groups * CG && Kw == KW, "aptai_posconv_gemm: built for 48 channels per group and 128 taps (H=%ld groups=%ld Kw=%ld)",
+                  (long)H, (long)groups, (long)Kw);
+    APTAI_REQUIRE(B > 0 && Tp > 0 && Tp % FR == 0, "aptai_posconv_gemm: Tp=%ld must be a positive multiple of %d", (long)Tp, FR);
+    APTAI_REQUIRE(first_row >= 0 && first_row + KW - 1 <= 2 * pad, "aptai_posconv_gemm: first_row=%ld leaves the padded window (pad=%ld)",
+                  (long)first_row, (long)pad);
+    const long rows_p = Tp + 2 * pad;
+    PosconvArgs a;
+    a.xg = (const bf16_t*)xg + first_row * CG;
+    a.x_batch_stride = rows_p * CG;
+    a.x_group_stride = B * rows_p * CG;
+    a.w = (const bf16_t*)w; a.bias = bias; a.residual = (const bf16_t*)residual; a.out = (bf16_t*)out; a.out_pre = (bf16_t*)out_pre;
+    a.Tp = (int)Tp; a.H = (int)H; a.gelu = gelu;
+    APTAI_LAUNCH(posconv_kernel, dim3((unsigned)(Tp / FR), (unsigned)B, (unsigned)groups), dim3(256), X_BYTES + 2 * W_STAGE,
+                 (hipStream_t)stream, a);
+    APTAI_CHECK_LAUNCH("posconv_kernel");
+    return APTAI_OK;
+}

@@ -303,6 +303,19 @@ def posconv_weight(v, gain, groups, want_dgrad=True):
     return wf, wd, norm
 
 
+def posconv_gemm(xg, w, out, B, Tp, H, groups, Kw, pad, *, first_row=0, bias=None, gelu=False, residual=None, out_pre=None):
+    """Grouped positional convolution on the packed copy (aptai_posconv_gemm: 48 channels per group, 128 taps)."""
+    _dev(xg, w, out, bias, residual, out_pre)
+    _lib.call("aptai_posconv_gemm", xg.data_ptr(), first_row, w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), _ptr(out_pre),
+              B, Tp, H, groups, Kw, pad, int(gelu), _stream())
+    return out
+
+
+def posconv_kernel_fits(H: int, groups: int, Kw: int) -> bool:
+    import os
+    return H == groups * 48 and Kw == 128 and os.environ.get("APTAI_POSCONV_KERNEL", "1") != "0"      # =0: implicit-GEMM path (A/B)
+
+
 def posconv_pack(x, xg, B, Tp, H, groups, pad, *, u=None, rowmajor_out=None):
     _dev(x, xg, u, rowmajor_out)
     _lib.call("aptai_posconv_pack", x.data_ptr(), _ptr(u), xg.data_ptr(), _ptr(rowmajor_out), B, Tp, H, groups, pad, _stream())

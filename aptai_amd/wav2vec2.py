@@ -299,8 +299,11 @@ class _FrontImpl:
         K = Kw * Cg
         s.u = torch.empty((M, H), device=feats.device, dtype=torch.bfloat16) if need else None
         s.s = torch.empty((M, H), device=feats.device, dtype=torch.bfloat16)
-        ops.gemm(xg, s.wf, g.Tp, Cg, K, lda=Cg, ldb=K, out=s.s, ldc=H, bias=pcb, gelu=True, residual=h0, ldr=H, out_pre=s.u,
-                 batch=self._posconv_batch(Cg, rows_p, K))
+        if ops.posconv_kernel_fits(H, G, Kw):            # wav2vec2-base: dedicated Toeplitz-window kernel (csrc/posconv.hip)
+            ops.posconv_gemm(xg, s.wf, s.s, g.B, g.Tp, H, G, Kw, pad, bias=pcb, gelu=True, residual=h0, out_pre=s.u)
+        else:
+            ops.gemm(xg, s.wf, g.Tp, Cg, K, lda=Cg, ldb=K, out=s.s, ldc=H, bias=pcb, gelu=True, residual=h0, ldr=H, out_pre=s.u,
+                     batch=self._posconv_batch(Cg, rows_p, K))
         s.xg_key = "pc_x"
         self.model._scratch_owner["pc_x"] = s
         if cfg.do_stable_layer_norm:
@@ -332,8 +335,11 @@ class _FrontImpl:
         ops.posconv_pack(ds, dug, g.B, g.Tp, H, G, pad, u=s.u, rowmajor_out=du_rm)
         dpcb = ops.colsum(du_rm, M, H)
         dh0 = torch.empty((M, H), device=dy.device, dtype=torch.bfloat16)
-        ops.gemm(dug[Cg:], s.wd, g.Tp, Cg, K, lda=Cg, ldb=K, out=dh0, ldc=H, residual=ds, ldr=H,
-                 batch=self._posconv_batch(Cg, rows_p, K))
+        if ops.posconv_kernel_fits(H, G, Kw):
+            ops.posconv_gemm(dug, s.wd, dh0, g.B, g.Tp, H, G, Kw, pad, first_row=1, residual=ds)
+        else:
+            ops.gemm(dug[Cg:], s.wd, g.Tp, Cg, K, lda=Cg, ldb=K, out=dh0, ldc=H, residual=ds, ldr=H,
+                     batch=self._posconv_batch(Cg, rows_p, K))
         xg, _, _, _ = self._packed(s.xg_key, dy.device)
         if self.model._scratch_owner.get(s.xg_key) is not s:
             ops.posconv_pack(s.h0, xg, g.B, g.Tp, H, G, pad)         # another forward reused the scratch: repack

@@ -136,6 +136,13 @@ int aptai_conv_weight_to_bf16(const float* src, void* dst, int64_t N, int64_t C,
  * scratch for the two-stage reduction; Kw must divide 256. */
 int aptai_posconv_weight(const float* v, const float* gain, float* norm_ws, void* w_fwd, void* w_dgrad, int64_t H,
                          int64_t groups, int64_t Kw, void* stream);
+/* The grouped convolution itself for 48 channels per group and 128 taps (wav2vec2-base), replacing the batched implicit GEMM:
+ * out[b*Tp+t][grp*48+n] = residual + act(bias + sum_{kw,c} xg[grp][b][first_row + t + kw][c] * w[grp][n][kw*48+c]);
+ * xg as produced by aptai_posconv_pack ([groups][B][pad+Tp+pad][48], gap rows zero), w = w_fwd (forward, first_row 0,
+ * bias + GELU, out_pre = pre-activation) or w_dgrad (data gradient, first_row 1); Tp % 128 == 0. */
+int aptai_posconv_gemm(const void* xg, int64_t first_row, const void* w, const float* bias, const void* residual, void* out,
+                       void* out_pre, int64_t B, int64_t Tp, int64_t H, int64_t groups, int64_t Kw, int64_t pad, int gelu,
+                       void* stream);
 /* x [B*Tp][H] bf16 -> group-major, zero-gapped xg [groups][B][pad+Tp+pad][Cg] (gap rows must be pre-zeroed once);
  * with u != null the packed value is x*gelu'(u) (backward of HF:362) and rowmajor_out also receives it. */
 int aptai_posconv_pack(const void* x, const void* u, void* xg, void* rowmajor_out, int64_t B, int64_t Tp, int64_t H,

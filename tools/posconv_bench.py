@@ -14,6 +14,13 @@ out = torch.empty(B * Tp, H, device="cuda", dtype=torch.bfloat16)
 bias = torch.randn(H, device="cuda")
 batch = dict(outer=B, inner=G, a=(rows_p * Cg, B * rows_p * Cg), b=(0, Cg * K), c=(Tp * H, Cg), bias=(0, Cg), res=(Tp * H, Cg), aux=(Tp * H, Cg))
 fl = 2.0 * B * Tp * H * K
-for tile in (128, 64):
+for tile in (128,):
     t = bench(lambda: ops.gemm(xg, wf, Tp, Cg, K, lda=Cg, ldb=K, out=out, ldc=H, bias=bias, gelu=True, batch=batch, tile=tile), iters=20)
     print(f"tile={tile}: {t:.1f} us  {fl/t/1e6:.0f} TF useful")
+res = torch.randn(B * Tp, H, device="cuda", generator=g).to(torch.bfloat16)
+ref = ops.gemm(xg, wf, Tp, Cg, K, lda=Cg, ldb=K, out=torch.empty_like(out), ldc=H, bias=bias, gelu=True, residual=res, ldr=H, batch=batch, tile=128)
+got = ops.posconv_gemm(xg, wf, torch.empty_like(out), B, Tp, H, G, Kw, pad, bias=bias, gelu=True, residual=res)
+torch.cuda.synchronize()
+print("posconv kernel vs implicit GEMM: max abs diff", (got.float() - ref.float()).abs().max().item(), "scale", ref.float().abs().max().item())
+t = bench(lambda: ops.posconv_gemm(xg, wf, out, B, Tp, H, G, Kw, pad, bias=bias, gelu=True, residual=res), iters=20)
+print(f"tile=posconv kernel: {t:.1f} us  {fl/t/1e6:.0f} TF useful")
