@@ -134,7 +134,119 @@ __global__ __launch_bounds__(256, 3) void posconv_kernel(PosconvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient: dW[grp][co][kw*48 + ci] = sum over the frames f of the packed copies of dU[f][co] * X[f + kw][ci]
+// (the zero gap rows between utterances make one long frame axis per group, exactly as the TN GEMM call did).
+// Both operands are frame-major ("K-major"): A[f][co] = dU rows (96 B), B[f][n] = X at byte 96 f + 2 n - the Toeplitz
+// window again, 64 frames x 128 columns = 6.3 KB instead of a 16 KB tile.  One block = 48 x 128 outputs of one group,
+// 4 waves x 32 columns, fragments through ds_read_b64_tr_b16 (per-lane addresses, so the 96-byte row stride needs no
+// re-layout); every MFMA tile is real where the 128 x 128 TN tile computed 128 rows for 48.
+constexpr int WG_NT = 128;                                // output columns per block
+constexpr int WG_STAGE = 2 * 512 * 16;                    // A (6144 B used) + B window (6304 B used), 8 KiB each
+
+struct PosconvWgradArgs {
+    const bf16_t* du; const bf16_t* x;                    // group-major packed copies, [G][frames_total][48]
+    long group_stride;                                    // elements
+    float* dw;                                            // [G][48][6144]
+    int nkt;                                              // K-tiles of 64 frames
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* base, int lane, int ks) {
+    // 16 rows (the 32 contiguous bytes at `base`, 8-B piece p) x 32 k of a frame-major tile with 96-byte rows
+    const int gq = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3;
+    const char* a0 = base + (ks * 32 + gq * 8 + qq) * (CG * 2) + p * 8;
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)a0);
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(a0 + 4 * CG * 2));
+    short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(256, 3) void posconv_wgrad_kernel(PosconvWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * WG_NT, grp = blockIdx.y;
+    const bf16_t* du = a.du + (long)grp * a.group_stride;
+    const bf16_t* xb = a.x + (long)grp * a.group_stride + n0;
+    // per-thread staging sources, advanced by 64 frames per K-tile; chunks beyond the used bytes re-read the last one
+    const bf16_t* pa[2];
+    const bf16_t* pb[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = it * 256 + tid;
+        pa[it] = du + (long)(c < 384 ? c : 383) * 8;
+        pb[it] = xb + (long)(c < 394 ? c : 393) * 8;
+    }
+    auto stage = [&](char* buf) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pa[it]), LDS_PTR(buf + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            pa[it] += 64 * CG;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pb[it]), LDS_PTR(buf + 8192 + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            pb[it] += 64 * CG;
+        }
+    };
+    stage(smem);
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < a.nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = kt & 1;
+        if (kt + 1 < a.nkt) stage(smem + (cur ^ 1) * WG_STAGE);
+        const char* sa = smem + cur * WG_STAGE;
+        const char* sb = sa + 8192 + wave * 64;            // this wave's 32 columns (2 bytes each)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[3], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) af[i] = tr_frag(sa + i * 32, lane, ks);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = tr_frag(sb + j * 32, lane, ks);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* out = a.dw + (long)grp * CG * KTOT;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int m = i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wave * 32 + j * 16 + (lane >> 4) * 4;
+            *(f32x4*)(out + (long)m * KTOT + n) = acc[i][j];
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int aptai_posconv_wgrad(const void* du_g, const void* x_g, float* dw, int64_t B, int64_t Tp, int64_t H, int64_t groups,
+                                   int64_t Kw, int64_t pad, void* stream) {
+    APTAI_REQUIRE(du_g && x_g && dw, "aptai_posconv_wgrad: null pointer");
+    APTAI_REQUIRE(groups > 0 && H == groups * CG && Kw == KW && 2 * pad == KW, "aptai_posconv_wgrad: built for 48 channels per group, 128 taps, pad 64");
+    const long rows_p = Tp + 2 * pad;
+    const long frames = B * rows_p - 2 * pad;              // dU frame f pairs with X frames f .. f+127
+    APTAI_REQUIRE(B > 0 && Tp > 0 && frames % 64 == 0, "aptai_posconv_wgrad: %ld frames per group is not a multiple of 64", (long)frames);
+    PosconvWgradArgs a;
+    a.du = (const bf16_t*)du_g + pad * CG;                 // dU of output frame t lives at packed row pad + t
+    a.x = (const bf16_t*)x_g;
+    a.group_stride = B * rows_p * CG;
+    a.dw = dw;
+    a.nkt = (int)(frames / 64);
+    APTAI_LAUNCH(posconv_wgrad_kernel, dim3((unsigned)(KTOT / WG_NT), (unsigned)groups), dim3(256), 2 * WG_STAGE, (hipStream_t)stream, a);
+    APTAI_CHECK_LAUNCH("posconv_wgrad_kernel");
+    return APTAI_OK;
+}
 
 extern "C" int aptai_posconv_gemm(const void* xg, int64_t first_row, const void* w, const float* bias, const void* residual, void* out,
                                   void* out_pre, int64_t B, int64_t Tp, int64_t H, int64_t groups, int64_t Kw, int64_t pad, int gelu,

@@ -311,6 +311,13 @@ def posconv_gemm(xg, w, out, B, Tp, H, groups, Kw, pad, *, first_row=0, bias=Non
     return out
 
 
+def posconv_wgrad(du_g, x_g, dw, B, Tp, H, groups, Kw, pad):
+    """dW of the grouped positional convolution from the two packed copies (aptai_posconv_wgrad); dw fp32 [groups][48][Kw*48]."""
+    _dev(du_g, x_g, dw)
+    _lib.call("aptai_posconv_wgrad", du_g.data_ptr(), x_g.data_ptr(), dw.data_ptr(), B, Tp, H, groups, Kw, pad, _stream())
+    return dw
+
+
 def posconv_kernel_fits(H: int, groups: int, Kw: int) -> bool:
     import os
     return H == groups * 48 and Kw == 128 and os.environ.get("APTAI_POSCONV_KERNEL", "1") != "0"      # =0: implicit-GEMM path (A/B)

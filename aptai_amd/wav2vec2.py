@@ -345,8 +345,11 @@ class _FrontImpl:
             ops.posconv_pack(s.h0, xg, g.B, g.Tp, H, G, pad)         # another forward reused the scratch: repack
         kred = g.B * rows_p - 2 * pad
         dwf = torch.empty((G, Cg, K), device=dy.device, dtype=torch.float32)
-        ops.gemm(dug[pad * Cg:], xg, Cg, K, kred, a_kmajor=True, b_kmajor=True, out_f32=True, lda=Cg, ldb=Cg, out=dwf, ldc=K,
-                 batch=dict(outer=1, inner=G, a=(0, g.B * rows_p * Cg), b=(0, g.B * rows_p * Cg), c=(0, Cg * K)))
+        if ops.posconv_kernel_fits(H, G, Kw):
+            ops.posconv_wgrad(dug, xg, dwf, g.B, g.Tp, H, G, Kw, pad)
+        else:
+            ops.gemm(dug[pad * Cg:], xg, Cg, K, kred, a_kmajor=True, b_kmajor=True, out_f32=True, lda=Cg, ldb=Cg, out=dwf, ldc=K,
+                     batch=dict(outer=1, inner=G, a=(0, g.B * rows_p * Cg), b=(0, g.B * rows_p * Cg), c=(0, Cg * K)))
         # weight-norm backward (parameter-sized fp32 math): w = g * v / ||v||
         dW = dwf.view(G, Cg, Kw, Cg).permute(0, 1, 3, 2).reshape(H, Cg, Kw).contiguous()
         v = pcv.detach()

@@ -143,6 +143,10 @@ int aptai_posconv_weight(const float* v, const float* gain, float* norm_ws, void
 int aptai_posconv_gemm(const void* xg, int64_t first_row, const void* w, const float* bias, const void* residual, void* out,
                        void* out_pre, int64_t B, int64_t Tp, int64_t H, int64_t groups, int64_t Kw, int64_t pad, int gelu,
                        void* stream);
+/* Weight gradient of the same convolution: dw[grp][co][kw*48+ci] (fp32, overwritten) = sum_f du_g[grp][pad + f][co] *
+ * x_g[grp][f + kw][ci] over the frame axis of the packed copies (gap rows are zero), replacing the batched TN GEMM. */
+int aptai_posconv_wgrad(const void* du_g, const void* x_g, float* dw, int64_t B, int64_t Tp, int64_t H, int64_t groups, int64_t Kw,
+                        int64_t pad, void* stream);
 /* x [B*Tp][H] bf16 -> group-major, zero-gapped xg [groups][B][pad+Tp+pad][Cg] (gap rows must be pre-zeroed once);
  * with u != null the packed value is x*gelu'(u) (backward of HF:362) and rowmajor_out also receives it. */
 int aptai_posconv_pack(const void* x, const void* u, void* xg, void* rowmajor_out, int64_t B, int64_t Tp, int64_t H,
