@@ -54,6 +54,9 @@ class GraphedAPTAIStep:
         self.tv_tgt = torch.zeros((B, g.T, model.n_tv), device=dev, dtype=torch.float32)
         self.phn_tgt = torch.zeros((B, g.T), device=dev, dtype=torch.int64)
         self.salt = torch.zeros(2, device=dev, dtype=torch.int32)
+        self._salt_ring = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(4)]
+        self._salt_events = [None] * 4
+        self._salt_turn = 0
         self._salt_gen = np.random.RandomState(0xC0FFEE + w.base_seed)
         _lib.call("aptai_set_seed_salt", self.salt.data_ptr())
         self.set_batch(batch)
@@ -78,13 +81,17 @@ class GraphedAPTAIStep:
 
     def _host_randomness(self):
         cfg, g = self.cfg, self.g
-        self.salt.copy_(torch.from_numpy(self._salt_gen.randint(-2 ** 31, 2 ** 31 - 1, size=2).astype(np.int32)))
-        if cfg.apply_spec_augment and cfg.mask_time_prob > 0:
-            am = torch.arange(g.T)[None, :] < self.frame_lens_cpu[:, None]
-            full = bool(am.all())
-            m = hostlogic.compute_mask_indices((g.B, g.T), cfg.mask_time_prob, cfg.mask_time_length,
-                                               attention_mask=None if full else am, min_masks=cfg.mask_time_min_masks)
-            self.spec.copy_(torch.from_numpy(m.astype(np.uint8)))
+        # the per-step salt travels through a small ring of pinned buffers (a pageable H2D copy would block the host until
+        # the GPU has drained); the SpecAugment mask is sampled by a kernel inside the front segment from the same salt
+        slot = self._salt_turn
+        self._salt_turn = (slot + 1) % len(self._salt_ring)
+        if self._salt_events[slot] is not None:
+            self._salt_events[slot].synchronize()
+        self._salt_ring[slot].copy_(torch.from_numpy(self._salt_gen.randint(-2 ** 31, 2 ** 31 - 1, size=2).astype(np.int32)))
+        self.salt.copy_(self._salt_ring[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._salt_events[slot] = ev
         keep = [True] * cfg.num_hidden_layers
         if cfg.layerdrop > 0:
             keep = [float(torch.rand([], generator=self.w._layerdrop_gen)) >= cfg.layerdrop for _ in keep]
@@ -130,6 +137,9 @@ class GraphedAPTAIStep:
                         w.encoder.layer_norm.weight, w.encoder.layer_norm.bias]
         self.g_front = mk()
         with torch.cuda.graph(self.g_front, pool=pool):
+            if embed is not None and cfg.apply_spec_augment and cfg.mask_time_prob > 0:
+                ops.spec_augment_mask(self.lens_i32, g.B, g.T, cfg.mask_time_prob, cfg.mask_time_length, cfg.mask_time_min_masks,
+                                      _seed(seed, 77), out=self.spec)        # fresh spans on every replay (salted seed)
             feats = w._conv_forward(self.audio, g, save=False)[0]
             (h,), self.s_front = self.front.fwd(feats, self.fparams, True)
         self.X = [h]

@@ -328,6 +328,15 @@ def posconv_pack(x, xg, B, Tp, H, groups, pad, *, u=None, rowmajor_out=None):
     _lib.call("aptai_posconv_pack", x.data_ptr(), _ptr(u), xg.data_ptr(), _ptr(rowmajor_out), B, Tp, H, groups, pad, _stream())
 
 
+def spec_augment_mask(frame_lens_i32, B, T, mask_prob, mask_length, min_masks, seed, out=None):
+    """SpecAugment time mask [B][T] uint8 sampled on the device (no host round trip of the lengths)."""
+    _dev(frame_lens_i32, out)
+    m = out if out is not None else torch.empty((B, T), device=frame_lens_i32.device, dtype=torch.uint8)
+    _lib.call("aptai_spec_augment_mask", frame_lens_i32.data_ptr(), m.data_ptr(), B, T, float(mask_prob), mask_length, min_masks, seed,
+              _stream())
+    return m
+
+
 def frame_mask_fwd(h, lens_i32, spec_mask_u8, embed, B, Tp, T, H):
     _dev(h, lens_i32, spec_mask_u8, embed)
     _lib.call("aptai_frame_mask_fwd", h.data_ptr(), lens_i32.data_ptr(), _ptr(spec_mask_u8), _ptr(embed), B, Tp, T, H, _stream())

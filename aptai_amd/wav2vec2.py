@@ -244,6 +244,7 @@ class _LayerImpl:
 _SIDE_STREAMS = {}
 _GROUPED_WGRAD = os.environ.get("APTAI_GROUPED_WGRAD", "1") != "0"
 _PRE_DGELU = os.environ.get("APTAI_PRE_DGELU", "1") != "0"
+_SPEC_ON_DEVICE = os.environ.get("APTAI_SPEC_ON_DEVICE", "1") != "0"      # =0: numpy sampler with HF's RNG order (host round trip)
 _USE_SIDE_STREAM = os.environ.get("APTAI_SIDE_STREAM", "0") != "0"     # measured neutral on MI355X (A/B 15.95 vs 15.98 ms/step)
 
 
@@ -785,12 +786,18 @@ class Wav2Vec2Model(nn.Module):
             if mask_time_indices is not None:
                 spec = torch.as_tensor(mask_time_indices).to(dev).to(torch.uint8).contiguous()
             elif cfg.mask_time_prob > 0 and training:
-                am = None
-                if attention_mask is not None:
-                    am = (torch.arange(g.T)[None, :] < frame_lens.cpu()[:, None])
-                m = hostlogic.compute_mask_indices((B, g.T), cfg.mask_time_prob, cfg.mask_time_length, attention_mask=am,
-                                                   min_masks=cfg.mask_time_min_masks)
-                spec = torch.from_numpy(m.astype(np.uint8)).to(dev)
+                if _SPEC_ON_DEVICE:
+                    # sampled by a kernel from the device-resident lengths: no device->host copy (a 2.3 ms stall of the eager
+                    # loop per step).  Same rule as HF `_compute_mask_indices`, counter-hash draws instead of numpy's.
+                    spec = ops.spec_augment_mask(lens_i32, B, g.T, cfg.mask_time_prob, cfg.mask_time_length, cfg.mask_time_min_masks,
+                                                 _seed(seed, 77))
+                else:
+                    am = None
+                    if attention_mask is not None:
+                        am = (torch.arange(g.T)[None, :] < frame_lens.cpu()[:, None])
+                    m = hostlogic.compute_mask_indices((B, g.T), cfg.mask_time_prob, cfg.mask_time_length, attention_mask=am,
+                                                       min_masks=cfg.mask_time_min_masks)
+                    spec = torch.from_numpy(m.astype(np.uint8)).to(dev)
         fp = self.feature_projection
         embed = getattr(self, "masked_spec_embed", None)
         front = _FrontImpl(cfg, g, lens_i32, spec, training, seed, self)

@@ -147,6 +147,11 @@ int aptai_posconv_gemm(const void* xg, int64_t first_row, const void* w, const f
  * x_g[grp][f + kw][ci] over the frame axis of the packed copies (gap rows are zero), replacing the batched TN GEMM. */
 int aptai_posconv_wgrad(const void* du_g, const void* x_g, float* dw, int64_t B, int64_t Tp, int64_t H, int64_t groups, int64_t Kw,
                         int64_t pad, void* stream);
+/* SpecAugment time mask sampled on the device (HF:101-217 `_compute_mask_indices` as called at HF:1292-1304): mask_u8 [B][T]
+ * (overwritten), frame_lens int32 [B] valid frames per utterance.  Same span-count rule and without-replacement span starts as
+ * the reference; counter-hash random stream keyed by `seed` (and the device seed salt). */
+int aptai_spec_augment_mask(const int32_t* frame_lens, void* mask_u8, int64_t B, int64_t T, float mask_prob, int64_t mask_length,
+                            int64_t min_masks, uint64_t seed, void* stream);
 /* x [B*Tp][H] bf16 -> group-major, zero-gapped xg [groups][B][pad+Tp+pad][Cg] (gap rows must be pre-zeroed once);
  * with u != null the packed value is x*gelu'(u) (backward of HF:362) and rowmajor_out also receives it. */
 int aptai_posconv_pack(const void* x, const void* u, void* xg, void* rowmajor_out, int64_t B, int64_t Tp, int64_t H,

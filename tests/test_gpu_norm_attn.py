@@ -1,5 +1,6 @@
 """GPU parity: LayerNorm fwd/bwd and the attention core fwd/bwd against fp32 torch on the CPU
 (inputs pre-rounded to bf16; outputs are bf16 -> tolerance 1e-2 of the tensor scale unless noted)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -129,3 +130,32 @@ def test_attention_dropout_consistency():
     lhs = (dV * V).sum().item()
     rhs = (dctx.float() * c1.float().cpu()).sum().item()
     assert abs(lhs - rhs) <= 2e-2 * (abs(rhs) + 50), (lhs, rhs)
+
+
+def test_spec_augment_mask_sampler_follows_the_hf_rule():
+    """aptai_spec_augment_mask: span count = int(p * len / L + eps) clamped as HF `_compute_mask_indices` does (so each row masks
+    between (n-1)*L+1.. and n*L frames, spans may overlap), spans stay inside the utterance (or clamp to the last frame), rows
+    differ, seeds differ, and the masked fraction over many draws matches the host sampler's."""
+    from aptai_amd import ops, hostlogic
+    B, T, L, p = 16, 499, 10, 0.05
+    lens = torch.tensor([499] * 8 + [399, 420, 450, 470, 480, 490, 30, 9], dtype=torch.int32).cuda()
+    counts = np.zeros(B)
+    prev = None
+    for seed in range(40):
+        m = ops.spec_augment_mask(lens, B, T, p, L, 2, seed * 7919 + 1).cpu().numpy()
+        assert m.shape == (B, T) and set(np.unique(m)) <= {0, 1}
+        for b in range(B):
+            n_on = int(m[b].sum())
+            ln = int(lens[b])
+            if ln - (L - 1) <= 0:
+                assert n_on == 0                                   # too short for one span
+                continue
+            assert 2 <= n_on <= 3 * L                              # 2 or 3 spans of 10 frames, possibly overlapping
+            assert m[b, ln:].sum() == 0 or ln == T                 # nothing beyond the utterance (starts < len - 9)
+        if prev is not None:
+            assert (m != prev).any()
+        prev = m
+        counts += m.sum(1)
+    dev_frac = counts[:8].mean() / 40 / T
+    host = np.mean([hostlogic.compute_mask_indices((8, T), p, L, min_masks=2, rng=np.random.RandomState(s)).mean() for s in range(40)])
+    assert abs(dev_frac - host) < 0.006, (dev_frac, host)
