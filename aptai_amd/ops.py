@@ -54,7 +54,9 @@ def set_gemm_probe(p: Optional["GemmProbe"]) -> None:
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # raw handle of torch's current stream; ~10x cheaper than torch.cuda.current_stream().cuda_stream, which was 0.9 ms of host
+    # time per eager train step (1000+ launches)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
