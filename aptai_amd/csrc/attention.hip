@@ -40,24 +40,31 @@ struct AttnArgs {
     int skip_pad_q;
 };
 
-// ---- LDS tile [rows][64] bf16, 128-B rows, 16-B chunk index XORed with (row & 7).
+// ---- LDS tile [rows][64] bf16, 128-B rows, 16-B chunk index XORed with tile_swz(row) = row bits (2, 3, 1) -> swizzle bits
+// (0, 1, 2).  Found by exhaustive search over the GF(2)-linear 3x5 maps: it is the simplest one for which BOTH access shapes
+// of these kernels are conflict-free - the 32-row ds_read_b128 fragments (lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}:
+// 16 distinct 16-byte bank groups) and the ds_read_b64_tr_b16 column reads (4 rows x 64 B per 32-lane group: rows of equal
+// parity must differ in chunk bit 2).  With the usual (row & 7) rocprofv3 counted 1.3-1.8 conflict cycles per LDS cycle here.
 // All per-lane LDS offsets are loop invariant and are computed ONCE per kernel (the per-tile instruction count, not the
 // MFMA rate, is what bounds these kernels at T ~ 500: every VALU instruction in the tile loop costs ~1/500 of it).
-__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ int tile_swz(int row) { return ((row >> 2) & 3) | (((row >> 1) & 1) << 2); }
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + ((chunk ^ tile_swz(row)) << 4); }
 
 struct LaneOffs {
     int rowk[4];      // row reads: byte offset of this lane's 16-B chunk for d-step ds (tile row = lane&31); + row_block*4096
-    int tr[2];        // transposed reads: byte offset for d-tile dt, depth block 0 (rows 4h+qq); + s*2048 (+1024 for the hi half)
+    int tr[2][2];     // transposed reads: [d-tile][lo / hi half], depth block 0 (rows 4h+qq and 4h+qq+8); + s*2048
 };
 __device__ __forceinline__ LaneOffs lane_offs(int lane) {
     LaneOffs o;
     const int r31 = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds) o.rowk[ds] = r31 * 128 + (((2 * ds + h) ^ (r31 & 7)) << 4);
+    for (int ds = 0; ds < 4; ++ds) o.rowk[ds] = tile_off(r31, 2 * ds + h);
     const int dgrp = (lane >> 4) & 1, i = lane & 15, qq = i >> 2, p = i & 3;
-    const int trow = 4 * h + qq;                          // (16*s + trow) & 7 == trow & 7, also for the +8 half
+    const int trow = 4 * h + qq;                          // rows 16*s + trow (+8): the swizzle reads row bits 1..3 only
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) o.tr[dt] = trow * 128 + (((dt * 4 + 2 * dgrp + (p >> 1)) ^ (trow & 7)) << 4) + ((p & 1) << 3);
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) o.tr[dt][hi] = tile_off(trow + 8 * hi, dt * 4 + 2 * dgrp + (p >> 1)) + ((p & 1) << 3);
     return o;
 }
 __device__ __forceinline__ bf16x8 rd_row(const char* tile, const LaneOffs& o, int row_block, int ds) {
@@ -65,9 +72,8 @@ __device__ __forceinline__ bf16x8 rd_row(const char* tile, const LaneOffs& o, in
 }
 // A operand (rows = tile columns d, depth = tile rows) for 32x32x16: element j <-> tile row 16*s + 8*(j>>2) + 4*h + (j&3)
 __device__ __forceinline__ bf16x8 rd_tr(const char* tile, const LaneOffs& o, int s, int dt) {
-    const char* p0 = tile + o.tr[dt] + s * 2048;
-    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p0);
-    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p0 + 1024));
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tile + o.tr[dt][0] + s * 2048));
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tile + o.tr[dt][1] + s * 2048));
     short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, r);
 }
