@@ -15,21 +15,41 @@
 
 namespace {
 
-constexpr int CG = 48, KW = 128, FR = 128;              // channels per group, taps, output frames per block
+constexpr int CG = 48, KW = 128, FR = 128;              // channels per group (base), taps, output frames per block
 constexpr int KTOT = KW * CG;                           // 6144
 constexpr int XROWS = FR + KW - 1;                      // 255 input frames
 constexpr int X_BYTES = 6 * 256 * 16;                   // 24 KiB (255 * 96 = 24480 B used)
 constexpr int W_STAGE = 512 * 16;                       // 8 KiB (48 rows x 128 B used)
 
 struct PosconvArgs {
-    const bf16_t* xg; long x_group_stride, x_batch_stride;   // elements: [G][B][rows_p][48]
-    const bf16_t* w;                                           // [G][48][6144]
+    const bf16_t* xg; long x_group_stride, x_batch_stride;   // elements: [G][B][rows_p][Cg]
+    const bf16_t* w;                                           // [G][Cg][128*Cg]
     const float* bias;                                         // [H] or null
     const bf16_t* residual;                                    // [B*Tp][H] or null
     bf16_t* out;                                               // [B*Tp][H]
     bf16_t* out_pre;                                           // pre-activation copy or null
     int Tp, H, gelu;
 };
+
+// epilogue of one 16 x 16 MFMA tile: the lane owns 4 consecutive channels of one frame
+__device__ __forceinline__ void posconv_store(const PosconvArgs& a, const f32x4 accv, long row, int col) {
+    float v[4] = {accv[0], accv[1], accv[2], accv[3]};
+    if (a.bias) {
+        const f32x4 bv = *(const f32x4*)(a.bias + col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+    }
+    if (a.out_pre) *(u32x2*)(a.out_pre + row * a.H + col) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    if (a.gelu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+    }
+    if (a.residual) {
+        const u32x2 rv = *(const u32x2*)(a.residual + row * a.H + col);
+        v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
+    }
+    *(u32x2*)(a.out + row * a.H + col) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+}
 
 __global__ __launch_bounds__(256, 3) void posconv_kernel(PosconvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,31 +126,91 @@ __global__ __launch_bounds__(256, 3) void posconv_kernel(PosconvArgs a) {
                 for (int j = 0; j < 3; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
     }
-
-    // ---- epilogue: lane owns 4 consecutive channels of one frame per MFMA tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const long row = (long)b * a.Tp + t0 + wave * 32 + i * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int col = grp * CG + j * 16 + (lane >> 4) * 4;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (a.bias) {
-                const f32x4 bv = *(const f32x4*)(a.bias + col);
+        for (int j = 0; j < 3; ++j) posconv_store(a, acc[i][j], row, grp * CG + j * 16 + (lane >> 4) * 4);
+    }
+}
+
+// ---- 64 channels per group (wav2vec2-large).  A 128-byte Toeplitz stride would put the 16 rows of a fragment read on the same
+// banks, so the window is stored with a 144-byte frame pitch (16 distinct 4-bank groups again) and every K-tile is exactly one
+// tap: A[t][kw, c] = window[(t + kw) * 144 + 2 c].  The padded pitch rules out the linear LDS-DMA copy: the window is loaded
+// through registers once.
+constexpr int CG2 = 64, PITCH2 = 144;
+constexpr int X2_BYTES = (XROWS + 1) * PITCH2;          // 36,864 B
+constexpr int W2_STAGE = CG2 * 128;                     // 8 KiB: [64][64] bf16
+
+__global__ __launch_bounds__(256, 3) void posconv64_kernel(PosconvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sX = smem;
+    char* sW = smem + X2_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * FR, b = blockIdx.y, grp = blockIdx.z;
+    const bf16_t* xsrc = a.xg + (long)grp * a.x_group_stride + (long)b * a.x_batch_stride + (long)t0 * CG2;
+    for (int c = tid; c < XROWS * 8; c += 256) {        // 255 frames x 8 chunks of 16 B
+        const int fr = c >> 3, ch = c & 7;
+        *(u32x4*)(sX + fr * PITCH2 + ch * 16) = *(const u32x4*)(xsrc + (long)fr * CG2 + ch * 8);
+    }
+    const bf16_t* wg = a.w + (long)grp * CG2 * (KW * CG2);
+    const bf16_t* pw[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bv[r];
-            }
-            if (a.out_pre) *(u32x2*)(a.out_pre + row * a.H + col) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-            if (a.gelu) {
+    for (int it = 0; it < 2; ++it) {
+        const int c = it * 256 + tid, row = c >> 3, pc = c & 7;
+        pw[it] = wg + (long)row * (KW * CG2) + ((pc ^ (row & 7)) << 3);
+    }
+    auto stage_w = [&](char* buf) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-            }
-            if (a.residual) {
-                const u32x2 rv = *(const u32x2*)(a.residual + row * a.H + col);
-                v[0] += lo_bf(rv[0]); v[1] += hi_bf(rv[0]); v[2] += lo_bf(rv[1]); v[3] += hi_bf(rv[1]);
-            }
-            *(u32x2*)(a.out + row * a.H + col) = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        for (int it = 0; it < 2; ++it) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pw[it]), LDS_PTR(buf + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            pw[it] += 64;
         }
+    };
+    stage_w(sW);
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int a_off = (wave * 32 + (lane & 15)) * PITCH2 + (lane >> 4) * 16;
+    int b_off[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = j * 16 + (lane & 15), q = ks * 4 + (lane >> 4);
+            b_off[j][ks] = row * 128 + ((q ^ (row & 7)) << 4);
+        }
+    for (int kt = 0; kt < KW; ++kt) {                   // one tap per K-tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int cur = kt & 1;
+        if (kt + 1 < KW) stage_w(sW + (cur ^ 1) * W2_STAGE);
+        const char* sw = sW + cur * W2_STAGE;
+        const char* sa = sX + a_off + kt * PITCH2;
+        bf16x8 af[2][2], bfr[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[ks][i] = *(const bf16x8*)(sa + i * (16 * PITCH2) + ks * 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[ks][j] = *(const bf16x8*)(sw + b_off[j][ks]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long row = (long)b * a.Tp + t0 + wave * 32 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) posconv_store(a, acc[i][j], row, grp * CG2 + j * 16 + (lane >> 4) * 4);
     }
 }
 
@@ -252,20 +332,22 @@ extern "C" int aptai_posconv_gemm(const void* xg, int64_t first_row, const void*
                                   void* out_pre, int64_t B, int64_t Tp, int64_t H, int64_t groups, int64_t Kw, int64_t pad, int gelu,
                                   void* stream) {
     APTAI_REQUIRE(xg && w && out, "aptai_posconv_gemm: null pointer");
-    APTAI_REQUIRE(groups > 0 && H == groups * CG && Kw == KW, "aptai_posconv_gemm: built for 48 channels per group and 128 taps (H=%ld groups=%ld Kw=%ld)",
-                  (long)H, (long)groups, (long)Kw);
+    APTAI_REQUIRE(groups > 0 && (H == groups * CG || H == groups * CG2) && Kw == KW,
+                  "aptai_posconv_gemm: built for 48 or 64 channels per group and 128 taps (H=%ld groups=%ld Kw=%ld)", (long)H, (long)groups, (long)Kw);
     APTAI_REQUIRE(B > 0 && Tp > 0 && Tp % FR == 0, "aptai_posconv_gemm: Tp=%ld must be a positive multiple of %d", (long)Tp, FR);
     APTAI_REQUIRE(first_row >= 0 && first_row + KW - 1 <= 2 * pad, "aptai_posconv_gemm: first_row=%ld leaves the padded window (pad=%ld)",
                   (long)first_row, (long)pad);
+    const long cg = H / groups;
     const long rows_p = Tp + 2 * pad;
     PosconvArgs a;
-    a.xg = (const bf16_t*)xg + first_row * CG;
-    a.x_batch_stride = rows_p * CG;
-    a.x_group_stride = B * rows_p * CG;
+    a.xg = (const bf16_t*)xg + first_row * cg;
+    a.x_batch_stride = rows_p * cg;
+    a.x_group_stride = B * rows_p * cg;
     a.w = (const bf16_t*)w; a.bias = bias; a.residual = (const bf16_t*)residual; a.out = (bf16_t*)out; a.out_pre = (bf16_t*)out_pre;
     a.Tp = (int)Tp; a.H = (int)H; a.gelu = gelu;
-    APTAI_LAUNCH(posconv_kernel, dim3((unsigned)(Tp / FR), (unsigned)B, (unsigned)groups), dim3(256), X_BYTES + 2 * W_STAGE,
-                 (hipStream_t)stream, a);
+    const dim3 grid((unsigned)(Tp / FR), (unsigned)B, (unsigned)groups);
+    if (cg == CG) APTAI_LAUNCH(posconv_kernel, grid, dim3(256), X_BYTES + 2 * W_STAGE, (hipStream_t)stream, a);
+    else APTAI_LAUNCH(posconv64_kernel, grid, dim3(256), X2_BYTES + 2 * W2_STAGE, (hipStream_t)stream, a);
     APTAI_CHECK_LAUNCH("posconv_kernel");
     return APTAI_OK;
 }

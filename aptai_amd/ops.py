@@ -320,9 +320,12 @@ def posconv_wgrad(du_g, x_g, dw, B, Tp, H, groups, Kw, pad):
     return dw
 
 
-def posconv_kernel_fits(H: int, groups: int, Kw: int) -> bool:
+def posconv_kernel_fits(H: int, groups: int, Kw: int, wgrad: bool = False) -> bool:
+    """The dedicated kernels cover 48 channels per group (wav2vec2-base; forward, data and weight gradient) and 64 (large; forward
+    and data gradient).  APTAI_POSCONV_KERNEL=0 forces the batched implicit-GEMM path (A/B)."""
     import os
-    return H == groups * 48 and Kw == 128 and os.environ.get("APTAI_POSCONV_KERNEL", "1") != "0"      # =0: implicit-GEMM path (A/B)
+    ok = (H == groups * 48) or (H == groups * 64 and not wgrad)
+    return ok and Kw == 128 and os.environ.get("APTAI_POSCONV_KERNEL", "1") != "0"
 
 
 def posconv_pack(x, xg, B, Tp, H, groups, pad, *, u=None, rowmajor_out=None):

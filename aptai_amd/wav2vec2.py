@@ -346,7 +346,7 @@ class _FrontImpl:
             ops.posconv_pack(s.h0, xg, g.B, g.Tp, H, G, pad)         # another forward reused the scratch: repack
         kred = g.B * rows_p - 2 * pad
         dwf = torch.empty((G, Cg, K), device=dy.device, dtype=torch.float32)
-        if ops.posconv_kernel_fits(H, G, Kw):
+        if ops.posconv_kernel_fits(H, G, Kw, wgrad=True):
             ops.posconv_wgrad(dug, xg, dwf, g.B, g.Tp, H, G, Kw, pad)
         else:
             ops.gemm(dug[pad * Cg:], xg, Cg, K, kred, a_kmajor=True, b_kmajor=True, out_f32=True, lda=Cg, ldb=Cg, out=dwf, ldc=K,
