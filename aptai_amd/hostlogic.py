@@ -185,3 +185,38 @@ def ctc_best_path(logits: np.ndarray, length: int, blank: int = 0) -> np.ndarray
     keep[1:] = ids[1:] != ids[:-1]
     ids = ids[keep]
     return ids[ids != blank].astype(np.int64)
+
+
+# ----------------------------------------------------------------------------- target preparation
+def interpolate_signal(org_sig, tar_len: int) -> np.ndarray:
+    """Linear resampling of a [frames] or [frames][channels] track to ``tar_len`` points that span the same time range
+    (data/dataset_hprc.py:2307-2313: 100 Hz trajectories -> the encoder's 49 Hz frames).  scipy's interp1d(kind='linear') on the
+    integer grid, written out: out[i] = (1-w) x[floor(p)] + w x[floor(p)+1] at p = i (n-1)/(tar_len-1)."""
+    x = np.asarray(org_sig, dtype=np.float64)
+    n = x.shape[0]
+    pos = np.linspace(0, n - 1, tar_len)
+    lo = np.clip(np.floor(pos).astype(np.int64), 0, max(n - 2, 0))
+    w = pos - lo
+    hi = np.minimum(lo + 1, n - 1)
+    if x.ndim > 1:
+        w = w.reshape((-1,) + (1,) * (x.ndim - 1))
+    return x[lo] + (x[hi] - x[lo]) * w
+
+
+def match_phonemes_to_frames(phoneme_boundaries, phoneme_list, frame_duration: float = 0.02) -> list:
+    """Frame labels from phoneme END boundaries (utility.py:317-342): frame k covers [k*step, (k+1)*step) centiseconds with
+    step = int(frame_duration*100); it takes the first phoneme whose boundary falls inside, otherwise keeps the previous frame's
+    label (None before the first hit).  The reference's O(frames x phonemes) scan as one searchsorted."""
+    b = np.asarray(phoneme_boundaries, dtype=np.float64)
+    step = int(frame_duration * 100)
+    stop = int(b[-1] * 100) + 1
+    out, current = [], None
+    starts = np.arange(0, stop, step)
+    for fs in starts:
+        lo, hi = fs / 100.0, (fs + int(frame_duration * 100)) / 100.0
+        hit = np.nonzero((b >= lo) & (b < hi))[0]
+        if hit.size:
+            current = phoneme_list[int(hit[0])]
+        out.append(current)
+    return out
+

@@ -384,7 +384,38 @@ def case_metrics(name="metrics_small"):
     save(name, dict(case=name), arrays)
 
 
-CASES = {"ops": case_ops, "metrics": case_metrics, "pr_mini": case_pr_base_mini, "pr_base": case_pr_base, "aptai_large": case_aptai_large,
+def case_dataprep(name="dataprep_small"):
+    """Target preparation the corpus scripts apply before the batch reaches the model:
+    `interpolate_signal` (data/dataset_hprc.py:2307-2313: 100 Hz trajectories -> 49 Hz frames) and
+    `match_phonemes_to_frames` (utility.py:317-342: phoneme boundaries -> 20 ms frame labels)."""
+    import importlib
+    for missing in ("soundfile", "textgrid", "praatio", "tgt", "seaborn"):
+        if missing not in sys.modules:
+            try:
+                importlib.import_module(missing)
+            except Exception:
+                sys.modules[missing] = types.ModuleType(missing)
+    sys.path.insert(0, os.path.join(REF, "data"))
+    import dataset_hprc as ref_data
+    import utility as ref_util
+    arrays = {}
+    rng = np.random.RandomState(9)
+    for i, (n, c, tar) in enumerate([(1000, 9, 490), (337, 1, 165), (50, 3, 50), (2, 2, 7)]):
+        sig = rng.randn(n, c) if c > 1 else rng.randn(n)
+        arrays[f"interp/{i}/in"] = sig
+        arrays[f"interp/{i}/tar_len"] = np.int64(tar)
+        arrays[f"interp/{i}/out"] = np.asarray(ref_data.interpolate_signal(sig, tar))
+    for i, nph in enumerate([12, 3, 1]):
+        bounds = np.round(np.cumsum(rng.uniform(0.03, 0.4, nph)), 2)
+        labels = rng.randint(1, 40, nph)
+        got = ref_util.match_phonemes_to_frames(list(bounds), list(labels), frame_duration=0.02)
+        arrays[f"match/{i}/bounds"] = bounds
+        arrays[f"match/{i}/labels"] = labels
+        arrays[f"match/{i}/out"] = np.array([-1 if v is None else int(v) for v in got], dtype=np.int64)
+    save(name, dict(case=name), arrays)
+
+
+CASES = {"ops": case_ops, "metrics": case_metrics, "dataprep": case_dataprep, "pr_mini": case_pr_base_mini, "pr_base": case_pr_base, "aptai_large": case_aptai_large,
          "force": case_force}
 
 if __name__ == "__main__":

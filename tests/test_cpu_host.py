@@ -138,3 +138,18 @@ def test_product_never_imports_the_oracle_and_has_no_cpu_fallback():
         ops.gemm(x, x, 128, 128, 64)
     with pytest.raises(AptaiHipError):
         ops.layernorm_fwd(torch.zeros(4, 256, dtype=torch.bfloat16), torch.ones(256), torch.zeros(256), 1e-5)
+
+
+def test_target_preparation_matches_reference_vectors(golden):
+    """interpolate_signal / match_phonemes_to_frames against vectors generated by importing the reference
+    (tests/golden/make_golden.py::case_dataprep)."""
+    import numpy as np
+    from aptai_amd import hostlogic
+    z, _ = golden("dataprep_small")
+    for i in range(4):
+        got = hostlogic.interpolate_signal(z[f"interp/{i}/in"], int(z[f"interp/{i}/tar_len"]))
+        np.testing.assert_allclose(got, z[f"interp/{i}/out"], rtol=1e-12, atol=1e-12)
+    for i in range(3):
+        got = hostlogic.match_phonemes_to_frames(z[f"match/{i}/bounds"].tolist(), z[f"match/{i}/labels"].tolist(), frame_duration=0.02)
+        assert [-1 if v is None else int(v) for v in got] == z[f"match/{i}/out"].tolist()
+
