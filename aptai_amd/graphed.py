@@ -1,7 +1,7 @@
 """hipGraph-captured APTAI train step (HIP streams + graphs instead of a tracing compiler).
 
-The eager drop-in loop (``model(epoch, **batch)``; ``loss.backward()``; ``optimizer.step()``) issues ~1100 kernel
-launches per step from Python; on a loaded host that, not the GPU, sets the step time.  ``GraphedAPTAIStep`` captures
+The eager drop-in loop (``model(epoch, **batch)``; ``loss.backward()``; ``optimizer.step()``) issues ~340 kernel
+launches per step from Python and autograd callbacks; that, not the GPU, sets its step time (13.7 ms against 10.4 ms of kernels).  ``GraphedAPTAIStep`` captures
 the same kernels, through the same C ABI and the same fwd/bwd implementations the autograd path uses, into SEGMENT
 graphs:
 
@@ -10,10 +10,12 @@ graphs:
 and replays them (~30 ``hipGraphLaunch`` per step).  Host-side randomness keeps the reference's semantics:
  * LayerDrop (HF:701-703 / 774-776): a dropped layer's two graphs are simply not replayed (its activations / gradients are
    forwarded by one device copy) and its parameters get ``grad = None`` that step, exactly like eager;
- * SpecAugment (HF:101-217): the span mask is sampled on the host as before and copied into a static device buffer;
+ * SpecAugment (HF:101-217): the span mask is sampled by a kernel at the head of the front segment (ops.spec_augment_mask:
+   HF's span-count rule, fresh spans on every replay through the salted seed) - no host copy, no synchronisation;
  * dropout: kernels XOR a per-step device salt into their counter-RNG seeds (``aptai_set_seed_salt``), so every replay
    draws fresh masks while the forward and backward of one step regenerate identical ones.
-The optimiser stays eager (torch's fused Adam: a handful of launches).
+The optimiser step is issued eagerly after the last segment (aptai_amd.optim.Adam: one launch per parameter group; or any
+torch optimiser).  Nothing in a step synchronises host and device.
 """
 from __future__ import annotations
 

@@ -527,7 +527,8 @@ class Wav2Vec2Model(nn.Module):
         hit = self._cache.get(key)
         # In training mode the copies are rebuilt on every forward: optimisers with fused kernels (e.g.
         # torch.optim.Adam(fused=True)) update parameters in place WITHOUT bumping Tensor._version, so a version check
-        # would silently keep stale weights.  The casts are ~90 tiny launches per step.  Eval mode trusts the version.
+        # would silently keep stale weights.  Eval mode trusts the version.  (The transformer-layer copies go through
+        # _refresh_layer_copies / ops.CastPlan instead: one launch, or none when the optimiser publishes them.)
         trainable = self.training and any(p.requires_grad for p in params)
         if mode != "build" and not trainable and hit is not None and hit[0] == ver:
             return hit[1]
