@@ -1038,18 +1038,19 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         const long t192 = ceil_div(d->M, T3_BM) * ceil_div(d->N, T3_BN) * nbatch * nsplit;
         if (tile == 128 && !d->a_kmajor && !d->b_kmajor && d->M % T3_BM == 0 && d->N % T3_BN == 0 && t192 > 192 && t192 <= 256)
             tile = 192;
-        // single-round GEMMs that fill the 512 slots of the 128-tile kernel badly run as 64 x 128 tiles on 768 slots (3 blocks per
-        // CU): base dgrads [8192] x 768 (384 tiles -> 768: 49.1 vs 54.9 us at K = 3072, 38.0 vs 42.9 us at K = 2304), large
-        // [4096] x 1024 outputs (256 tiles -> 512: 13.7 vs 17.5 us at K = 1024, 42.4 vs 47.5 us at K = 4096, dgrads 41-52 vs
-        // 52-65 us).  Multi-round shapes measured no gain and keep the 128-tile kernel.
+        // GEMMs that fill the 512 slots of the 128-tile kernel badly run as 64 x 128 tiles on 768 slots (3 blocks per CU): base
+        // dgrads [8192] x 768 (384 tiles -> 768: 49.1 vs 54.9 us at K = 3072, 38.0 vs 42.9 us at K = 2304), base QKV (1152 tiles =
+        // 2.25 rounds -> 2304 = 3 rounds), large [4096] x 1024 outputs (256 tiles -> 512: 13.7 vs 17.5 us at K = 1024, 42.4 vs
+        // 47.5 us at K = 4096, dgrads 41-52 vs 52-65 us).  Whole step: -0.25 ms from the multi-round cases alone.
+        // APTAI_GEMM_M64=0 disables the rule, =2 restricts it to single-round shapes (A/B).
         static int m64 = -1;
         if (m64 < 0) {
-            const char* e = getenv("APTAI_GEMM_M64");             // A/B switch
+            const char* e = getenv("APTAI_GEMM_M64");
             m64 = e ? atoi(e) : 1;
         }
         const long t64 = ceil_div(d->M, 64) * ceil_div(d->N, BN) * nbatch * nsplit;
         const double e64 = (double)t64 / (double)(ceil_div(t64, 768) * 768);
-        if (m64 && tile == 128 && !d->a_kmajor && d->M % 64 == 0 && t128 <= 512 && e64 >= 1.2 * e128) tile = 64;
+        if (m64 && tile == 128 && !d->a_kmajor && d->M % 64 == 0 && (t128 <= 512 || m64 != 2) && e64 >= 1.2 * e128) tile = 64;
     }
     if (tile == 64 && d->a_kmajor) tile = 128;            // 64-row tiles need a K-contiguous A
     int rc;
