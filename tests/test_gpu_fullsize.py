@@ -78,3 +78,26 @@ def test_stochastic_train_step_is_reproducible(setup):
     assert (res[0][1] is None) == (res[1][1] is None)
     if res[0][1] is not None:
         assert torch.equal(res[0][1], res[1][1])
+
+
+def test_thirty_second_utterances_1499_frames():
+    """BASELINE configs[4] shape (30 s clips, 1499 frames -> Tp = 1536): the attention / positional-conv / conv-stack kernels at
+    3x the tuned sequence length - frame-count arithmetic, utterance independence bit for bit, finite gradients."""
+    from aptai_amd.config import W2V2Config
+    from oracle import synth
+    from test_gpu_aptai import _build
+    cfg = W2V2Config.base(vocab_size=46, num_hidden_layers=2, layerdrop=0.0)
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), 0)
+    model = _build(cfg, sd)
+    batch = {k: v.cuda() for k, v in synth.synth_aptai_batch(cfg, 2, 480000, seed=4).items()}
+    model.eval()
+    with torch.no_grad():
+        both = model(0, **batch)
+        one = model(0, **{k: v[1:2] for k, v in batch.items()})
+    assert both["tvs_pred"].shape == (2, 1499, 9)
+    assert torch.equal(both["tvs_pred"][1:2], one["tvs_pred"])
+    model.train()
+    out = model(0, **batch)
+    out["loss"].backward()
+    g = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(g) > 20 and all(torch.isfinite(x).all() for x in g)
