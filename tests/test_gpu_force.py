@@ -206,3 +206,34 @@ def test_force_aptai_b2_against_oracle():
     for b in range(2):
         assert out["pred_frame_phns"][b] == ref["pred_frame_phns"][b]                  # alignment indices bit-exact
     check(2e-3)
+
+
+def test_force_aptai_config3_size_step():
+    """BASELINE configs[2] at full size (wav2vec2-base + forced-alignment heads, 16 x 10 s): one training step through the frozen
+    encoder (inference), CrossAttention, forward-sum CTC, BiLSTM and the TV regression - shapes, padding conventions, finite
+    gradients on the head parameters only, alignment rows that stay inside each utterance's phoneme list."""
+    from oracle import synth
+    from aptai_amd.config import W2V2Config
+    z, meta = load_golden("force_aptai_1x2s")
+    pr_cfg = W2V2Config.from_any(meta["pr_cfg"])
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, meta["vocab_len"]), meta["seed"])
+    model, _ = _build(meta, sd)
+    model.train()
+    B, S = 16, 160000
+    batch = {k: v.cuda() for k, v in synth.synth_aptai_batch(pr_cfg, B, S, seed=8, n_phn=40).items()}
+    g = torch.Generator().manual_seed(5)
+    lists = [torch.randint(2, 40, (int(torch.randint(20, 56, (1,), generator=g)),), generator=g).numpy() for _ in range(B)]
+    batch["phoneme_labels"] = torch.zeros(B, 4, dtype=torch.int32).cuda()
+    out = model(0, **batch, _phn_pred_list=lists)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert out["tvs_pred"].shape == (B, 499, 9)
+    for k in ("loss", "tv_loss", "align_loss"):
+        assert np.isfinite(out[k].item()), k
+    assert len(out["pred_frame_phns"]) == B
+    for b in range(B):
+        frames = out["pred_frame_phns"][b]
+        assert set(int(v) for v in frames) <= set(int(v) for v in lists[b])          # aligned ids come from the utterance's own list
+    heads = [(n, p) for n, p in model.named_parameters() if not n.startswith("w2v2_pr.") and p.requires_grad]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in heads), [n for n, p in heads if p.grad is None]
+    assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("w2v2_pr."))
