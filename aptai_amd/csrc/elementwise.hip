@@ -129,6 +129,53 @@ __global__ __launch_bounds__(256) void posconv_weight_kernel(const float* __rest
     }
 }
 
+// ---- weight-norm backward of the positional conv (w = gain * v / ||v||_(0,1) per tap, HF:340-356) from the weight gradient in the
+// forward GEMM layout dwf[grp][n][kk*Cg + c]:   dot[kk] = sum_{o,c} dW[o][c][kk] v[o][c][kk],   dgain[kk] = dot / norm,
+// dv = gain / norm * (dW - v * dot / norm^2).  One block per output channel o: its dwf row is transposed through LDS so both the
+// dwf reads and the v / dv accesses are contiguous.  Pass 1 writes per-block tap sums, pass 2 (after the tiny final sum) writes dv.
+__global__ __launch_bounds__(256) void posconv_wn_dot_kernel(const float* __restrict__ dwf, const float* __restrict__ v,
+                                                             float* __restrict__ partial, int Cg, int Kw) {
+    extern __shared__ float slab[];                    // [Kw][Cg + 1]: dwf row o as [kk][c]
+    __shared__ float red[256];
+    const int o = blockIdx.x, n = Cg * Kw;
+    for (int i = threadIdx.x; i < n; i += 256) slab[(i / Cg) * (Cg + 1) + i % Cg] = dwf[(long)o * n + i];
+    __syncthreads();
+    float s = 0.f;                                     // thread t owns tap t % Kw (256 % Kw == 0)
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = i / Kw, kk = i % Kw;
+        s = fmaf(slab[kk * (Cg + 1) + c], v[(long)o * n + i], s);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < Kw) {
+        float t = 0.f;
+        for (int j = threadIdx.x; j < 256; j += Kw) t += red[j];
+        partial[(long)o * Kw + threadIdx.x] = t;
+    }
+}
+__global__ void posconv_wn_final_kernel(const float* __restrict__ partial, const float* __restrict__ norm, float* __restrict__ dot,
+                                        float* __restrict__ dgain, int H, int Kw) {
+    const int kk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kk >= Kw) return;
+    float s = 0.f;
+    for (int o = 0; o < H; ++o) s += partial[(long)o * Kw + kk];
+    dot[kk] = s;
+    dgain[kk] = s / norm[kk];
+}
+__global__ __launch_bounds__(256) void posconv_wn_apply_kernel(const float* __restrict__ dwf, const float* __restrict__ v,
+                                                               const float* __restrict__ gain, const float* __restrict__ norm,
+                                                               const float* __restrict__ dot, float* __restrict__ dv, int Cg, int Kw) {
+    extern __shared__ float slab[];
+    const int o = blockIdx.x, n = Cg * Kw;
+    for (int i = threadIdx.x; i < n; i += 256) slab[(i / Cg) * (Cg + 1) + i % Cg] = dwf[(long)o * n + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = i / Kw, kk = i % Kw;
+        const float nr = norm[kk];
+        dv[(long)o * n + i] = gain[kk] / nr * (slab[kk * (Cg + 1) + c] - v[(long)o * n + i] * dot[kk] / (nr * nr));
+    }
+}
+
 // x [B*Tp][H] -> Xg[grp][b][pad | Tp | pad][Cg]  (gap rows are never written: the buffer is zeroed once)
 // optional: multiply by gelu'(u) first (du = dy * gelu'(u)) and also emit the row-major product.
 __global__ void posconv_pack_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ u, bf16_t* __restrict__ xg,
@@ -428,6 +475,25 @@ extern "C" int aptai_spec_augment_mask(const int32_t* frame_lens, void* mask_u8,
     APTAI_LAUNCH(spec_mask_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, frame_lens, (uint8_t*)mask_u8, (int)T, mask_prob,
                  (int)mask_length, (int)min_masks, (uint32_t)seed, (uint32_t)(seed >> 32), aptai_seed_salt());
     APTAI_CHECK_LAUNCH("spec_mask_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_posconv_weight_bwd(const float* dw_fwd, const float* v, const float* gain, const float* norm, float* dv, float* dgain,
+                                       float* workspace, int64_t H, int64_t groups, int64_t Kw, void* stream) {
+    APTAI_REQUIRE(dw_fwd && v && gain && norm && dv && dgain && workspace, "aptai_posconv_weight_bwd: null pointer");
+    APTAI_REQUIRE(groups > 0 && H % groups == 0 && Kw > 0 && 256 % Kw == 0, "aptai_posconv_weight_bwd: H=%ld groups=%ld Kw=%ld", (long)H, (long)groups, (long)Kw);
+    const int Cg = (int)(H / groups);
+    const size_t slab_bytes = (size_t)Kw * (Cg + 1) * 4;
+    APTAI_REQUIRE(slab_bytes <= 64 * 1024, "aptai_posconv_weight_bwd: slab of %ld bytes exceeds the LDS budget", (long)slab_bytes);
+    float* partial = workspace;                         // [H][Kw]
+    float* dot = workspace + H * Kw;                    // [Kw]
+    hipStream_t st = (hipStream_t)stream;
+    APTAI_LAUNCH(posconv_wn_dot_kernel, dim3((unsigned)H), dim3(256), slab_bytes, st, dw_fwd, v, partial, Cg, (int)Kw);
+    APTAI_CHECK_LAUNCH("posconv_wn_dot_kernel");
+    APTAI_LAUNCH(posconv_wn_final_kernel, dim3((unsigned)ceil_div(Kw, 128)), dim3(128), 0, st, (const float*)partial, norm, dot, dgain, (int)H, (int)Kw);
+    APTAI_CHECK_LAUNCH("posconv_wn_final_kernel");
+    APTAI_LAUNCH(posconv_wn_apply_kernel, dim3((unsigned)H), dim3(256), slab_bytes, st, dw_fwd, v, gain, norm, (const float*)dot, dv, Cg, (int)Kw);
+    APTAI_CHECK_LAUNCH("posconv_wn_apply_kernel");
     return APTAI_OK;
 }
 

@@ -305,6 +305,18 @@ def posconv_weight(v, gain, groups, want_dgrad=True):
     return wf, wd, norm
 
 
+def posconv_weight_bwd(dw_fwd, v, gain, norm, groups):
+    """Weight-norm backward of the positional conv: (dv [H][Cg][Kw], dgain [Kw]) from the weight gradient in the forward layout."""
+    _dev(dw_fwd, v, gain, norm)
+    H, Cg, Kw = v.shape
+    dv = torch.empty_like(v)
+    dgain = torch.empty(Kw, device=v.device, dtype=torch.float32)
+    ws = torch.empty((H + 1) * Kw, device=v.device, dtype=torch.float32)
+    _lib.call("aptai_posconv_weight_bwd", dw_fwd.data_ptr(), v.data_ptr(), gain.data_ptr(), norm.data_ptr(), dv.data_ptr(), dgain.data_ptr(),
+              ws.data_ptr(), H, groups, Kw, _stream())
+    return dv, dgain
+
+
 def posconv_gemm(xg, w, out, B, Tp, H, groups, Kw, pad, *, first_row=0, bias=None, gelu=False, residual=None, out_pre=None):
     """Grouped positional convolution on the packed copy (aptai_posconv_gemm: 48 channels per group, 128 taps)."""
     _dev(xg, w, out, bias, residual, out_pre)

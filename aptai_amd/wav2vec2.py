@@ -352,13 +352,8 @@ class _FrontImpl:
             ops.gemm(dug[pad * Cg:], xg, Cg, K, kred, a_kmajor=True, b_kmajor=True, out_f32=True, lda=Cg, ldb=Cg, out=dwf, ldc=K,
                      batch=dict(outer=1, inner=G, a=(0, g.B * rows_p * Cg), b=(0, g.B * rows_p * Cg), c=(0, Cg * K)))
         # weight-norm backward (parameter-sized fp32 math): w = g * v / ||v||
-        dW = dwf.view(G, Cg, Kw, Cg).permute(0, 1, 3, 2).reshape(H, Cg, Kw).contiguous()
-        v = pcv.detach()
-        norm = s.norm.view(1, 1, Kw)
-        gain = pcg.detach().view(1, 1, Kw)
-        dot = (dW * v).sum(dim=(0, 1), keepdim=True)
-        dpcg = (dot / norm).reshape(pcg.shape)
-        dpcv = gain / norm * (dW - v * dot / (norm * norm))
+        dpcv, dgain = ops.posconv_weight_bwd(dwf, pcv.detach().contiguous(), pcg.detach().reshape(-1).contiguous(), s.norm, G)
+        dpcg = dgain.reshape(pcg.shape)
         # ---- mask + projection + LN
         dembed = ops.frame_mask_bwd(dh0, self.lens, self.spec, g.B, g.Tp, g.T, H, want_dembed=embed is not None)
         if s.p_fp > 0:

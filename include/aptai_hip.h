@@ -136,6 +136,10 @@ int aptai_conv_weight_to_bf16(const float* src, void* dst, int64_t N, int64_t C,
  * scratch for the two-stage reduction; Kw must divide 256. */
 int aptai_posconv_weight(const float* v, const float* gain, float* norm_ws, void* w_fwd, void* w_dgrad, int64_t H,
                          int64_t groups, int64_t Kw, void* stream);
+/* Backward of that weight-norm parametrisation: from dw_fwd fp32 [groups][Cg][Kw*Cg] (the weight gradient in the forward layout)
+ * to dv [H][Cg][Kw] and dgain [Kw] (HF parametrizations.weight.original1 / original0).  workspace fp32 [(H + 1) * Kw]. */
+int aptai_posconv_weight_bwd(const float* dw_fwd, const float* v, const float* gain, const float* norm, float* dv, float* dgain,
+                             float* workspace, int64_t H, int64_t groups, int64_t Kw, void* stream);
 /* The grouped convolution itself for 48 channels per group and 128 taps (wav2vec2-base), replacing the batched implicit GEMM:
  * out[b*Tp+t][grp*48+n] = residual + act(bias + sum_{kw,c} xg[grp][b][first_row + t + kw][c] * w[grp][n][kw*48+c]);
  * xg as produced by aptai_posconv_pack ([groups][B][pad+Tp+pad][48], gap rows zero), w = w_fwd (forward, first_row 0,
