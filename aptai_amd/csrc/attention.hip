@@ -35,7 +35,7 @@ struct AttnArgs {
     const uint32_t* salt;
     // backward
     const bf16_t* dctx;
-    const float* delta;
+    float* delta;
     bf16_t* dqkv;
     int skip_pad_q;
 };
@@ -224,38 +224,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     if (a.lse2 && h == 0) a.lse2[((long)b * a.heads + hd) * a.Tp + q] = fmaf(m_run, c, fast_log2(l_tot));
 }
 
-// ================================================================================== delta = rowsum(dO * O)
-// 8 lanes per (row, head): 8 elements each (16-B bf16 + 32-B fp32 loads), shuffle-reduce inside the 8-lane group
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx, const float* __restrict__ o32,
-                                  float* __restrict__ delta, int B, int Tp, int H, int heads) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long item = gid >> 3;                               // (row, head)
-    const int sub = (int)(gid & 7);
-    const long total = (long)B * Tp * heads;
-    if (item >= total) return;
-    const long row = item / heads;
-    const int hd = (int)(item % heads);
-    const long off = row * H + hd * HD + sub * 8;
-    const u32x4 d = *(const u32x4*)(dctx + off);
-    float v = 0.f;
-    if (o32) {
-        const f32x4 a0 = *(const f32x4*)(o32 + off), a1 = *(const f32x4*)(o32 + off + 4);
-        v = lo_bf(d[0]) * a0[0] + hi_bf(d[0]) * a0[1] + lo_bf(d[1]) * a0[2] + hi_bf(d[1]) * a0[3] + lo_bf(d[2]) * a1[0] +
-            hi_bf(d[2]) * a1[1] + lo_bf(d[3]) * a1[2] + hi_bf(d[3]) * a1[3];
-    } else {
-        const u32x4 o = *(const u32x4*)(ctx + off);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v += lo_bf(d[r]) * lo_bf(o[r]) + hi_bf(d[r]) * hi_bf(o[r]);
-    }
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    if (sub == 0) {
-        const long bb = row / Tp, q = row % Tp;
-        delta[(bb * heads + hd) * Tp + q] = v;
-    }
-}
-
 // ================================================================================== backward: dK, dV
 // grid (Tp/128, heads, B); wave w owns keys key0 = kt*128 + w*32 .. +31; loops over 32-query tiles.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
@@ -413,7 +381,28 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
         df[ds] = *(const bf16x8*)(Dg + ds * 16 + h * 8);
     }
     const float lse_q = a.lse2[((long)b * a.heads + hd) * a.Tp + q];
-    const float del_q = a.delta[((long)b * a.heads + hd) * a.Tp + q];
+    // delta = rowsum(dO * O) of this lane's query: each half-wave lane holds 32 of the 64 head dims (the dO fragments it
+    // feeds the MFMAs with); the fp32 context keeps it accurate.  Written once for the dK/dV kernel, which is launched after.
+    float del_q = 0.f;
+    if (a.o32) {
+        const float* Og = a.o32 + (rowbase + q) * a.ldo + hd * HD;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            const f32x4 o0 = *(const f32x4*)(Og + ds * 16 + h * 8), o1 = *(const f32x4*)(Og + ds * 16 + h * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) del_q = fmaf((float)df[ds][j], o0[j], fmaf((float)df[ds][j + 4], o1[j], del_q));
+        }
+    } else {
+        const bf16_t* Og = a.ctx + (rowbase + q) * a.ldo + hd * HD;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            const bf16x8 o = *(const bf16x8*)(Og + ds * 16 + h * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) del_q = fmaf((float)df[ds][j], (float)o[j], del_q);
+        }
+    }
+    del_q += __shfl_xor(del_q, 32, 64);
+    if (h == 0) a.delta[((long)b * a.heads + hd) * a.Tp + q] = del_q;
     f32x16 dQT[2];
     dQT[0] = dQT[1] = (f32x16)(0.f);
     const int nk = (len + 31) >> 5;
@@ -518,16 +507,13 @@ extern "C" int aptai_attention_bwd(const void* qkv, const int32_t* lens, const v
     int rc = fill_args(a, "aptai_attention_bwd", qkv, lens, B, Tp, H, heads, scale, dropout_p, seed);
     if (rc) return rc;
     APTAI_REQUIRE(ctx && dctx && lse2 && delta_ws && dqkv, "aptai_attention_bwd: null pointer");
-    a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.lse2 = (float*)lse2; a.delta = delta_ws; a.dqkv = (bf16_t*)dqkv;
+    a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.lse2 = (float*)lse2; a.delta = delta_ws; a.o32 = (float*)ctx_f32; a.dqkv = (bf16_t*)dqkv;
     a.skip_pad_q = dctx_zero_beyond_len;
-    const long waves = (long)B * Tp * heads;
-    APTAI_LAUNCH(attn_delta_kernel, dim3((unsigned)ceil_div(waves * 8, 256)), dim3(256), 0, stream,
-                       (const bf16_t*)dctx, (const bf16_t*)ctx, ctx_f32, delta_ws, (int)B, (int)Tp, (int)H, (int)heads);
-    APTAI_CHECK_LAUNCH("attn_delta_kernel");
     dim3 grid((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B);
-    APTAI_LAUNCH(attn_bwd_dkdv_kernel, grid, dim3(256), 0, stream, a);
-    APTAI_CHECK_LAUNCH("attn_bwd_dkdv_kernel");
+    // dQ first: it computes delta for its own queries and leaves it in delta_ws for the dK/dV kernel
     APTAI_LAUNCH(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, a);
     APTAI_CHECK_LAUNCH("attn_bwd_dq_kernel");
+    APTAI_LAUNCH(attn_bwd_dkdv_kernel, grid, dim3(256), 0, stream, a);
+    APTAI_CHECK_LAUNCH("attn_bwd_dkdv_kernel");
     return APTAI_OK;
 }
