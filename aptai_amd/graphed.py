@@ -19,6 +19,7 @@ torch optimiser).  Nothing in a step synchronises host and device.
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
@@ -71,15 +72,49 @@ class GraphedAPTAIStep:
 
     # ------------------------------------------------------------------ inputs
     def set_batch(self, batch: Dict[str, torch.Tensor]) -> None:
+        """Copies a batch (the collate_fn's dict, host or device tensors) into the static input buffers of the graphs.
+        Host tensors go through a two-slot ring of pinned staging buffers and asynchronous copies on the step's stream:
+        10.7 ms/step against 10.3 with the batch resident (pageable copies, which block the host until the GPU has drained:
+        34 ms/step)."""
         cfg, g = self.cfg, self.g
-        self.audio.copy_(batch["audio_inputs"].float())
         lens_cpu = batch["audio_lengths"].detach().cpu().long()
         fl = hostlogic.feat_extract_output_lengths(lens_cpu, cfg.conv_kernel, cfg.conv_stride).clamp(min=1, max=g.T)
         self.frame_lens_cpu = fl
-        self.lens_i32.copy_(fl.to(torch.int32))
         tracks = [batch[k] for k in batch if k not in ("audio_inputs", "audio_lengths", "phn_frames_49hz", "phoneme_labels")]
+        if batch["audio_inputs"].device.type == "cpu":
+            # staging copies through numpy: single-threaded memcpy / cast.  torch's copy_ goes parallel above 32 K elements
+            # and the OpenMP workers then spin on the cores the launching thread needs (host time per step 8 -> 19 ms).
+            st = self._host_stage()
+            np.copyto(st["audio_np"], batch["audio_inputs"].detach().numpy(), casting="same_kind")
+            np.copyto(st["lens_np"], fl.numpy(), casting="same_kind")
+            for j, t in enumerate(tracks):                       # f64 (B, T) tracks -> one (B, T, n_tv) f32 block
+                st["tv_np"][:, :, j] = t.detach().numpy()
+            np.copyto(st["phn_np"], batch["phn_frames_49hz"].numpy(), casting="same_kind")
+            for dst, key in ((self.audio, "audio"), (self.lens_i32, "lens"), (self.tv_tgt, "tv"), (self.phn_tgt, "phn")):
+                dst.copy_(st[key], non_blocking=True)
+            st["event"] = torch.cuda.Event()
+            st["event"].record()
+            return
+        self.audio.copy_(batch["audio_inputs"].float())
+        self.lens_i32.copy_(fl.to(torch.int32))
         self.tv_tgt.copy_(torch.stack(tracks, dim=-1).float())
         self.phn_tgt.copy_(batch["phn_frames_49hz"])
+
+    def _host_stage(self):
+        ring = getattr(self, "_stage_ring", None)
+        if ring is None:
+            mk = lambda ref: torch.empty(ref.shape, dtype=ref.dtype).pin_memory()
+            ring = [dict(audio=mk(self.audio), lens=mk(self.lens_i32), tv=mk(self.tv_tgt), phn=mk(self.phn_tgt), event=None)
+                    for _ in range(2)]
+            for st in ring:
+                for key in ("audio", "lens", "tv", "phn"):
+                    st[key + "_np"] = st[key].numpy()            # views of the pinned buffers
+            self._stage_ring, self._stage_turn = ring, 0
+        st = ring[self._stage_turn]
+        self._stage_turn ^= 1
+        if st["event"] is not None:
+            st["event"].synchronize()                            # the copies that last read this slot have finished
+        return st
 
     def _host_randomness(self):
         cfg, g = self.cfg, self.g

@@ -73,14 +73,15 @@ def train(cfg, model, optimizer, lr_scheduler, train_dataloader, valid_dataloade
         sum_train_loss, steps = 0.0, 0
         model.train()
         for batch_idx, batch_x in enumerate(train_dataloader):
-            batch_x = {k: v.to(cfg.device) for k, v in batch_x.items()}
             if getattr(cfg, "graphed", False):
-                # same step as below, replayed as hipGraph segments; needs one batch shape (drop_last + fixed clip length)
+                # same step as below, replayed as hipGraph segments; needs one batch shape (drop_last + fixed clip length).
+                # The runner takes the collate_fn's HOST batch: pinned staging ring + asynchronous copies (set_batch)
                 if runner is None:
                     from .graphed import GraphedAPTAIStep
-                    runner = GraphedAPTAIStep(model, optimizer, batch_x)
+                    runner = GraphedAPTAIStep(model, optimizer, {k: v.to(cfg.device) for k, v in batch_x.items()})
                 outputs = runner.step(batch_x)
             else:
+                batch_x = {k: v.to(cfg.device) for k, v in batch_x.items()}
                 optimizer.zero_grad()
                 outputs = model(epoch, **batch_x)
                 outputs["loss"].backward()

@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of aptai_amd.optim.Adam")
+    ap.add_argument("--host-batch", action="store_true", help="hand the step a pinned HOST batch every iteration (PCIe-inclusive rate; "
+                    "never the headline value: DESIGN.md section 8)")
     ap.add_argument("--eager", action="store_true", help="drive the step through autograd (the drop-in loop) instead of hipGraphs")
     return ap.parse_args()
 
@@ -220,6 +222,9 @@ def main():
             reducer.remove()                 # gradients are reduced explicitly after the captured backward
         runner = GraphedAPTAIStep(model, opt, batch, reducer=reducer)
         step = runner.step
+        if args.host_batch:                  # the collate_fn's view of the boundary: host tensors in, H2D inside the step
+            host = {k: v.cpu().pin_memory() for k, v in batch.items()}
+            step = lambda: runner.step(host)
 
     for _ in range(args.warmup):
         step()
@@ -282,7 +287,8 @@ def main():
                        "frames_per_clip": int(S // 320 - (1 if S % 320 < 80 else 0)) if False else None,
                        "parallelism": f"dp{world}", "regularisers": "off" if args.no_regularisers else "HF defaults",
                        "optimizer": "Adam, fp32 state (torch fused)" if args.torch_adam else "Adam, fp32 state (aptai_adam_multi, refreshes the bf16 weight copies)",
-                       "execution": "eager autograd loop" if args.eager else "hipGraph segments (aptai_amd.graphed)"},
+                       "execution": "eager autograd loop" if args.eager else "hipGraph segments (aptai_amd.graphed)",
+                       "inputs": "pinned host batch copied in every step (PCIe-inclusive)" if args.host_batch else "resident in HBM"},
             "loss": round(loss, 5),
             "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM, NT layout (gemm_kernel / gemm192_kernel / gemm256_kernel <false,false,false>): every launch of the step",
                          "achieved": round(gemm_tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",

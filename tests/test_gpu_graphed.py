@@ -96,3 +96,38 @@ def test_eager_loop_sees_fused_optimizer_updates():
     ref = heads_ref.aptai_forward(sdc, cfg, cb["audio_inputs"], cb["audio_lengths"], cb["phn_frames_49hz"], [cb[n] for n in TV],
                                   training=False)["loss"].item()
     assert abs(got - ref) <= 2e-2 * abs(ref), (got, ref)
+
+
+def test_graphed_step_takes_host_batches():
+    """The collate_fn's view of the boundary: a new HOST batch handed to every replay (pinned staging ring, asynchronous
+    copies) gives the same losses as the eager loop on the same batches, in order."""
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.graphed import GraphedAPTAIStep
+    from oracle import synth
+    from test_gpu_aptai import _build
+    cfg = W2V2Config.base(num_hidden_layers=2, hidden_dropout=0., activation_dropout=0., attention_dropout=0.,
+                          feat_proj_dropout=0., final_dropout=0., layerdrop=0., apply_spec_augment=False, vocab_size=46)
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), 0)
+    host_batches = [synth.synth_aptai_batch(cfg, 2, 16000, seed=10 + i) for i in range(5)]
+    losses = {}
+    for mode in ("eager", "graph"):
+        model = _build(cfg, sd, tv_drop=0.0, phn_drop=0.0)
+        model.train()
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
+        ls = []
+        if mode == "eager":
+            for hb in host_batches:
+                opt.zero_grad(set_to_none=True)
+                out = model(0, **{k: v.cuda() for k, v in hb.items()})
+                out["loss"].backward()
+                opt.step()
+                ls.append(out["loss"].item())
+        else:
+            runner = GraphedAPTAIStep(model, opt, {k: v.cuda() for k, v in host_batches[0].items()})
+            outs = [runner.step(hb)["loss"].clone() for hb in host_batches]     # no host sync between the steps
+            ls = [o.item() for o in outs]
+            runner.close()
+        losses[mode] = ls
+    assert len(set(round(v, 4) for v in losses["eager"])) > 1                  # the batches differ
+    for a, b in zip(losses["eager"], losses["graph"]):
+        assert abs(a - b) <= 2e-3 * abs(a), losses
