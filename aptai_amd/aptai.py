@@ -54,8 +54,11 @@ def heads_fwd(h, tv_w, tv_b, ph_w, ph_b, st):
 def heads_bwd(s, st, gl):
     """Returns (dh, dW_tv, db_tv, dW_ph, db_ph); ``gl`` = device scalar gradient of the loss (or None = 1)."""
     g, M, H = st.g, st.g.M, s.h.shape[1]
+    # data parallel: normalise by the GLOBAL valid counts / world (dp.GlobalLossNorm) instead of this shard's own counts
+    norm = getattr(st, "norm_scalars", None)
     d_tvs, d_logits = ops.aptai_loss_bwd(s.tvs, st.tv_tgt, s.logits, _PADN, g.Tp, st.phn_tgt, g.B, g.T, s.n_tv, s.n_phn, st.w_mse,
-                                         st.w_ce, s.scalars, gl, ldd=_PADN)
+                                         st.w_ce, norm() if callable(norm) else (norm if norm is not None else s.scalars), gl,
+                                         ldd=_PADN)
     d_tvraw = torch.empty((M, _PADN), device=s.h.device, dtype=torch.bfloat16)
     ops.lowpass_fir(d_tvs, s.n_tv, g.T, st.taps, d_tvraw, _PADN, g.Tp, g.B, g.T, g.Tp, s.n_tv, _PADN)
     da_tv = ops.gemm(d_tvraw, s.wtv, M, H, _PADN, b_kmajor=True)
@@ -103,6 +106,7 @@ class APTAI(nn.Module):
             self.wav2vec2.freeze_feature_encoder()
         H = self.wav2vec2.config.hidden_size
 
+        self.dp_loss_norm = None       # aptai_amd.dp.GlobalLossNorm under data parallelism: masked means over the global batch
         self.tv_head = nn.Sequential(nn.Dropout(tv_drop), nn.Tanh(), nn.Linear(H, n_tv))
         self.tv_lowpass = LowPassFilterLayer(self.device, 10, 49, n_tv)
         self.phn_head = nn.Sequential(nn.Dropout(phn_drop), nn.LeakyReLU(), nn.Linear(H, n_phn))
@@ -118,6 +122,9 @@ class APTAI(nn.Module):
         st = SimpleNamespace(g=g, p_tv=self.tv_head[0].p if tr else 0.0, p_ph=self.phn_head[0].p if tr else 0.0,
                              seed=_seed(self.wav2vec2.base_seed, self.wav2vec2._step, 999), taps=self.tv_lowpass.taps(),
                              tv_tgt=tv_targets.contiguous(), phn_tgt=phn_targets.contiguous(), w_mse=0.5, w_ce=0.5)
+        if self.dp_loss_norm is not None and tr:
+            self.dp_loss_norm.begin(st.tv_tgt, st.phn_tgt)       # 2-scalar all-reduce under the head GEMMs
+            st.norm_scalars = self.dp_loss_norm.scalars           # resolved (waited for) in the backward
         return _HeadsFn.apply(h, self.tv_head[2].weight, self.tv_head[2].bias, self.phn_head[2].weight,
                               self.phn_head[2].bias, st)
 

@@ -187,6 +187,68 @@ class GradGroupReducer:
         self._pending = []
 
 
+class GlobalLossNorm:
+    """Masked-mean losses over the GLOBAL batch under data parallelism ("loss-mean subtlety").
+
+    models/aptai.py:89-100 divides the squared error by the number of valid TV elements of the batch and the cross-entropy
+    by the number of valid frames.  With utterances sharded over W ranks each rank sees only its own counts n_r, and the
+    average of per-rank means weights a frame of a short shard more than a frame of a long one.  This object makes the
+    averaged DP gradient equal the single-process gradient at the global batch: the backward normalises by n_global / W
+    instead of n_r (so the all-reduce AVERAGE of the W shard gradients is sum_r (shard sums) / n_global).  One 2-scalar
+    all-reduce per step, launched as soon as the targets are on the device and waited for just before the loss backward.
+
+    `begin(tv_tgt, phn_tgt)` -> launches; `scalars()` -> float32[5] device buffer in the layout of the loss kernels'
+    `scalars` (only [3] = TV elements and [4] = frames are read by aptai_aptai_loss_bwd)."""
+
+    def __init__(self, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._buf = None
+        self._work = None
+        self._stream = None
+
+    def buffer(self, device) -> torch.Tensor:
+        if self._buf is None or self._buf.device != torch.device(device):
+            self._buf = torch.ones(5, device=device, dtype=torch.float32)
+        return self._buf
+
+    def begin(self, tv_tgt: torch.Tensor, phn_tgt: Optional[torch.Tensor]) -> None:
+        buf = self.buffer(tv_tgt.device)
+        cur = torch.cuda.current_stream() if buf.is_cuda else None
+        if buf.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_stream(cur)
+        ctx = torch.cuda.stream(self._stream) if buf.is_cuda else _Null()
+        with ctx:
+            buf[3] = (tv_tgt != -100.0).sum()
+            buf[4] = (phn_tgt != 0).sum() if phn_tgt is not None else 1.0
+            if self.world > 1:
+                self._work = dist.all_reduce(buf, group=self.group, async_op=True)
+
+    def scalars(self) -> torch.Tensor:
+        """Waits for the counts and returns the buffer (n_global / W in [3], [4])."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            if self._buf.is_cuda:
+                with torch.cuda.stream(self._stream):
+                    self._buf.mul_(1.0 / self.world)
+            else:
+                self._buf.mul_(1.0 / self.world)
+        if self._buf.is_cuda:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        return self._buf
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 def shard_batch(batch: dict, rank: int, world: int) -> dict:
     """Contiguous utterance shards of a global batch dict."""
     out = {}

@@ -94,8 +94,9 @@ class _ForceHeadsFn(torch.autograd.Function):
         n_tv = l3_w.shape[0]
         gl = gloss.float().reshape(1)
         # ---- TV branch
-        d_tvs, _ = ops.aptai_loss_bwd(s.tvs, st.tv_tgt, s.dummy_logits, 1, Tp, s.dummy_phn, B, T, n_tv, 1, 1.0, 0.0, s.sc,
-                                      (0.4 * gl).contiguous(), ldd=8)
+        norm = getattr(st, "norm_scalars", None)             # data parallel: global valid TV count / world (dp.GlobalLossNorm)
+        d_tvs, _ = ops.aptai_loss_bwd(s.tvs, st.tv_tgt, s.dummy_logits, 1, Tp, s.dummy_phn, B, T, n_tv, 1, 1.0, 0.0,
+                                      norm() if norm is not None else s.sc, (0.4 * gl).contiguous(), ldd=8)
         d_tvraw = torch.empty((M, n_tv), device=dev, dtype=torch.float32)
         ops.lowpass_fir(d_tvs, n_tv, T, st.taps, d_tvraw, n_tv, Tp, B, T, Tp, n_tv, n_tv)
         dl3_w = ops.sgemm(d_tvraw, 1, n_tv, s.h1a, 256, 1, n_tv, 256, M)
@@ -149,6 +150,7 @@ class Force_APTAI(nn.Module):
         self.vocab = vocab
         self.device = device
         self.i = 0
+        self.dp_loss_norm = None       # aptai_amd.dp.GlobalLossNorm under data parallelism
         self.hidden_drop = 0.2
         self.rnn_drop = 0.1
         self.max_phn_seq_len = _NPHN
@@ -208,6 +210,11 @@ class Force_APTAI(nn.Module):
                              rnn_lens=torch.tensor(rnn_lens, dtype=torch.int32, device=dev),
                              text_lens=torch.tensor(phn_seq_lens, dtype=torch.int32, device=dev),
                              vocab_sizes=torch.tensor([n + 1 for n in phn_seq_lens], dtype=torch.int32, device=dev))
+        if getattr(self, "dp_loss_norm", None) is not None and tr:
+            # the TV loss is a masked mean over the batch (models/force_aptai.py:137-141); the alignment and CTC terms are
+            # means over utterances, which equal-sized shards already average exactly
+            self.dp_loss_norm.begin(st.tv_tgt, None)
+            st.norm_scalars = self.dp_loss_norm.scalars
         lstm = self.rnn.lstm
         P = (self.frame_lin.weight, self.frame_lin.bias, self.phn_emb_layer.weight, self.xatt.q.weight, self.xatt.q.bias,
              self.xatt.k.weight, self.xatt.k.bias, self.xatt.layer_norm.weight, self.xatt.layer_norm.bias,

@@ -197,6 +197,10 @@ class GraphedAPTAIStep:
         self.hparams = [model.tv_head[2].weight, model.tv_head[2].bias, model.phn_head[2].weight, model.phn_head[2].bias]
         self.st_heads = SimpleNamespace(g=g, p_tv=model.tv_head[0].p, p_ph=model.phn_head[0].p, seed=_seed(seed, 999),
                                         taps=model.tv_lowpass.taps(), tv_tgt=self.tv_tgt, phn_tgt=self.phn_tgt, w_mse=0.5, w_ce=0.5)
+        # data parallel: the loss backward inside the tail graph reads the global valid counts / world from this static buffer
+        self.loss_norm = getattr(model, "dp_loss_norm", None)
+        if self.loss_norm is not None:
+            self.st_heads.norm_scalars = self.loss_norm.buffer(self.dev)
         self.fin = _FinalLNImpl(cfg, g) if cfg.do_stable_layer_norm else None
         self.g_tail = mk()
         with torch.cuda.graph(self.g_tail, pool=pool):
@@ -242,6 +246,8 @@ class GraphedAPTAIStep:
             self.set_batch(batch)
         keep = self._host_randomness()
         L = self.cfg.num_hidden_layers
+        if self.loss_norm is not None:
+            self.loss_norm.begin(self.tv_tgt, self.phn_tgt)      # travels under the encoder forward
         self.g_prep.replay()
         self.g_front.replay()
         for i in range(L):
@@ -250,6 +256,8 @@ class GraphedAPTAIStep:
             else:
                 self.X[i + 1].copy_(self.X[i])
         red = self.group_reducer
+        if self.loss_norm is not None:
+            self.loss_norm.scalars()                 # counts launched at the top of the step have arrived
         self.g_tail.replay()
         if red is not None:
             red.launch("heads", [gt for p, gt in self.grads.items() if p.requires_grad and any(p is q for q in self.hparams)])

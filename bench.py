@@ -205,6 +205,9 @@ def main():
         from aptai_amd.optim import Adam
         opt = Adam(params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8).publish_to(model)
     reducer = GradBucketReducer(params, bucket_mb=48.0, comm_dtype=torch.bfloat16) if world > 1 else None
+    if world > 1:                            # masked-mean losses over the GLOBAL batch: DP gradients == single-process gradients
+        from aptai_amd.dp import GlobalLossNorm
+        model.dp_loss_norm = GlobalLossNorm()
     batch = synth_batch(cfg, B, S, args.n_tv, rank, device)
 
     if args.eager:
