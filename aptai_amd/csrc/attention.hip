@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; r += 2) {              // registers r, r+1 are consecutive keys: one hash per pair
                     const int key = kbase + kt2 * 32 + acc_row(r, h);
                     const uint32_t hsh = rng_hash(pbase + (uint32_t)(key >> 1), a.seed0, a.seed1);
-                    x[kt2][r] = (hsh & 0xffffu) >= a.thr16 ? x[kt2][r] * a.dscale : 0.f;
-                    x[kt2][r + 1] = (hsh >> 16) >= a.thr16 ? x[kt2][r + 1] * a.dscale : 0.f;
+                    x[kt2][r] = (hsh & 0xffffu) >= a.thr16 ? x[kt2][r] : 0.f;          // the 1/(1-p) factor rides on the
+                    x[kt2][r + 1] = (hsh >> 16) >= a.thr16 ? x[kt2][r + 1] : 0.f;      // final 1/l normalisation
                 }
         }
         l_run = fmaf(l_run, alpha, psum);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = __frcp_rn(l_tot);
+    const float inv = __frcp_rn(l_tot) * a.dscale;
     bf16_t* og = a.ctx + (rowbase + q) * a.ldo + hd * HD;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -326,10 +326,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 const uint32_t h0 = (lane & 1) ? other : mine, h1 = (lane & 1) ? mine : other;
                 const bool k0 = ((h0 >> hshift) & 0xffffu) >= a.thr16, k1 = ((h1 >> hshift) & 0xffffu) >= a.thr16;
                 const float p0 = pd[r], p1 = pd[r + 1];
-                dsv[r] = p0 * ((k0 ? dp[r] * a.dscale : 0.f) - dsv[r]);
-                dsv[r + 1] = p1 * ((k1 ? dp[r + 1] * a.dscale : 0.f) - dsv[r + 1]);
-                pd[r] = k0 ? p0 * a.dscale : 0.f;
-                pd[r + 1] = k1 ? p1 * a.dscale : 0.f;
+                // dS = dscale * P (keep * dP - delta / dscale), P_drop = dscale * keep * P: the dQ kernel left delta / dscale in
+                // a.delta and the 1/(1-p) factors are applied once to dK and dV in the epilogue
+                dsv[r] = p0 * ((k0 ? dp[r] : 0.f) - dsv[r]);
+                dsv[r + 1] = p1 * ((k1 ? dp[r + 1] : 0.f) - dsv[r + 1]);
+                pd[r] = k0 ? p0 : 0.f;
+                pd[r + 1] = k1 ? p1 : 0.f;
             }
         } else {
 #pragma unroll
@@ -351,10 +353,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = dt * 32 + 8 * g4 + 4 * h;
-            *(u32x2*)(dKg + d) = (u32x2){pack2bf(dKT[dt][4 * g4] * a.scale, dKT[dt][4 * g4 + 1] * a.scale),
-                                         pack2bf(dKT[dt][4 * g4 + 2] * a.scale, dKT[dt][4 * g4 + 3] * a.scale)};
-            *(u32x2*)(dVg + d) = (u32x2){pack2bf(dVT[dt][4 * g4], dVT[dt][4 * g4 + 1]),
-                                         pack2bf(dVT[dt][4 * g4 + 2], dVT[dt][4 * g4 + 3])};
+            const float ks = a.scale * a.dscale, vs = a.dscale;
+            *(u32x2*)(dKg + d) = (u32x2){pack2bf(dKT[dt][4 * g4] * ks, dKT[dt][4 * g4 + 1] * ks),
+                                         pack2bf(dKT[dt][4 * g4 + 2] * ks, dKT[dt][4 * g4 + 3] * ks)};
+            *(u32x2*)(dVg + d) = (u32x2){pack2bf(dVT[dt][4 * g4] * vs, dVT[dt][4 * g4 + 1] * vs),
+                                         pack2bf(dVT[dt][4 * g4 + 2] * vs, dVT[dt][4 * g4 + 3] * vs)};
         }
 }
 
@@ -402,6 +405,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
         }
     }
     del_q += __shfl_xor(del_q, 32, 64);
+    // with attention dropout dS = dscale * P (keep * dP - delta / dscale): both backward kernels work with delta / dscale and
+    // apply dscale = 1/(1-p) once in their epilogues (dscale = 1 without dropout)
+    del_q *= __frcp_rn(a.dscale);
     if (h == 0) a.delta[((long)b * a.heads + hd) * a.Tp + q] = del_q;
     f32x16 dQT[2];
     dQT[0] = dQT[1] = (f32x16)(0.f);
@@ -443,8 +449,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
             for (int r = 0; r < 16; r += 2) {
                 const int key = t * 32 + acc_row(r, h);
                 const uint32_t hsh = rng_hash(pbase + (uint32_t)(key >> 1), a.seed0, a.seed1);
-                dpT[r] = (hsh & 0xffffu) >= a.thr16 ? dpT[r] * a.dscale : 0.f;
-                dpT[r + 1] = (hsh >> 16) >= a.thr16 ? dpT[r + 1] * a.dscale : 0.f;
+                dpT[r] = (hsh & 0xffffu) >= a.thr16 ? dpT[r] : 0.f;
+                dpT[r + 1] = (hsh >> 16) >= a.thr16 ? dpT[r + 1] : 0.f;
             }
         }
 #pragma unroll
@@ -463,8 +469,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int d = dt * 32 + 8 * g4 + 4 * h;
-            *(u32x2*)(dQg + d) = (u32x2){pack2bf(dQT[dt][4 * g4] * a.scale, dQT[dt][4 * g4 + 1] * a.scale),
-                                         pack2bf(dQT[dt][4 * g4 + 2] * a.scale, dQT[dt][4 * g4 + 3] * a.scale)};
+            const float qs = a.scale * a.dscale;
+            *(u32x2*)(dQg + d) = (u32x2){pack2bf(dQT[dt][4 * g4] * qs, dQT[dt][4 * g4 + 1] * qs),
+                                         pack2bf(dQT[dt][4 * g4 + 2] * qs, dQT[dt][4 * g4 + 3] * qs)};
         }
 }
 
