@@ -108,13 +108,14 @@ def compute_mask_indices(shape, mask_prob: float, mask_length: int,
 # ----------------------------------------------------------------------------- optimiser schedule
 def get_lr_schedule(warmup_epochs: int, static_epochs: int, lr_decay: float) -> Callable[[int], float]:
     """LambdaLR factor of train/train_aptai.py:372-386 — note the 10x during warm-up/static phases."""
+    plateau_end = warmup_epochs + static_epochs
+
     def lambda_lr(epoch):
-        if epoch < warmup_epochs:
-            return 10. * (epoch + 1) / warmup_epochs
-        elif epoch < warmup_epochs + static_epochs:
-            return 10.
-        else:
-            return 10. * lr_decay ** (epoch - (warmup_epochs + static_epochs))
+        if epoch >= plateau_end:                       # exponential decay from the 10x plateau
+            return 10.0 * lr_decay ** (epoch - plateau_end)
+        if epoch >= warmup_epochs:                     # plateau
+            return 10.0
+        return 10.0 * (epoch + 1) / warmup_epochs      # linear warm-up to 10x
     return lambda_lr
 
 

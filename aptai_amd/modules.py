@@ -77,12 +77,12 @@ class PositionalEncoding(nn.Module):
         super().__init__()
         import math
         self.dropout = nn.Dropout(p=dropout)
-        position = torch.arange(max_len).unsqueeze(1)
-        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
-        pe = torch.zeros(max_len, 1, d_model)
-        pe[:, 0, 0::2] = torch.sin(position * div_term)
-        pe[:, 0, 1::2] = torch.cos(position * div_term)
-        self.register_buffer('pe', pe)
+        # fp32 throughout, like the reference, so the buffer is bit-identical: angle[t][i] = t * 10000^(-2i/d); the table
+        # interleaves sin (even columns) and cos (odd columns)
+        freq = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * (-math.log(10000.0) / d_model))
+        angle = torch.arange(max_len, dtype=torch.float32)[:, None] * freq[None, :]
+        table = torch.stack((angle.sin(), angle.cos()), dim=-1).reshape(max_len, 1, d_model)
+        self.register_buffer('pe', table.contiguous())
 
 
 class ForwardSumLoss(nn.Module):

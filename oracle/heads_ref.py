@@ -159,11 +159,10 @@ def ctc_best_path(logits: np.ndarray, blank: int = 0) -> np.ndarray:
 # ----------------------------------------------------------------------------- F2..F5 Force_APTAI pieces
 def positional_encoding(d_model: int = 128, max_len: int = 60) -> torch.Tensor:
     """models/modules.py:222-228 -> (max_len, 1, d_model)."""
-    position = torch.arange(max_len).unsqueeze(1)
-    div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
-    pe = torch.zeros(max_len, 1, d_model)
-    pe[:, 0, 0::2] = torch.sin(position * div_term)
-    pe[:, 0, 1::2] = torch.cos(position * div_term)
+    # angle[t][i] = t * 10000^(-2i/d) in fp32 like the reference; sin in the even columns, cos in the odd ones
+    freq = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32) * (-math.log(10000.0) / d_model))
+    angle = torch.arange(max_len, dtype=torch.float32)[:, None] * freq[None, :]
+    pe = torch.stack((angle.sin(), angle.cos()), dim=-1).reshape(max_len, 1, d_model).contiguous()
     return pe
 
 
