@@ -229,13 +229,16 @@ class GlobalLossNorm:
     def scalars(self) -> torch.Tensor:
         """Waits for the counts and returns the buffer (n_global / W in [3], [4])."""
         if self._work is not None:
-            self._work.wait()
-            self._work = None
+            # wait() orders the stream that is current when it is called behind the collective (NCCL/RCCL run it on their
+            # own stream): call it on the side stream, scale there, then let the caller's stream wait for the side stream
             if self._buf.is_cuda:
                 with torch.cuda.stream(self._stream):
+                    self._work.wait()
                     self._buf.mul_(1.0 / self.world)
             else:
+                self._work.wait()
                 self._buf.mul_(1.0 / self.world)
+            self._work = None
         if self._buf.is_cuda:
             torch.cuda.current_stream().wait_stream(self._stream)
         return self._buf

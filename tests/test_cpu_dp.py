@@ -127,3 +127,40 @@ def test_shard_batch_is_contiguous():
     from aptai_amd.dp import shard_batch
     b = {"a": torch.arange(8), "b": torch.arange(16).view(8, 2)}
     assert shard_batch(b, 1, 4)["a"].tolist() == [2, 3] and shard_batch(b, 3, 4)["b"].tolist() == [[12, 13], [14, 15]]
+
+
+def _norm_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from aptai_amd.dp import GlobalLossNorm
+    norm = GlobalLossNorm()
+    out = []
+    for step in range(2):                                       # the buffer is reused step after step
+        tv = torch.full((2, 10, 3), -100.0)
+        tv[:, :4 + 2 * rank + step] = 0.5                       # 2 * (4 + 2 rank + step) * 3 valid elements
+        phn = torch.zeros(2, 10, dtype=torch.long)
+        phn[:, :3 + rank] = 7                                   # 2 * (3 + rank) valid frames
+        norm.begin(tv, phn)
+        out.append(norm.scalars().clone().numpy())
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_global_loss_norm_counts_are_global_over_world():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_norm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(2):
+        n_tv = sum(2 * (4 + 2 * r + step) * 3 for r in range(world)) / world
+        n_ph = sum(2 * (3 + r) for r in range(world)) / world
+        for r in range(world):
+            assert res[r][step][3] == n_tv and res[r][step][4] == n_ph, (r, step, res[r][step])
