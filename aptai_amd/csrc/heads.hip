@@ -25,9 +25,13 @@ __global__ void fir_kernel(const float* __restrict__ x, long ldx, long rows_per_
         double acc = 0.0;
         if (c < C && t < T) {
             const float* xb = x + (long)b * rows_per_b_in * ldx + c;
+            // branch-free so the 51 strided loads are in flight together (the guarded form waited for each in turn, 20 us);
+            // a tap outside [0, T) reads frame t with weight 0: the sum and its order are unchanged
+#pragma unroll 17
             for (int j = 0; j < ntaps; ++j) {
                 const int tt = t + j - half;
-                if (tt >= 0 && tt < T) acc += tp[j] * (double)xb[(long)tt * ldx];
+                const bool in = (unsigned)tt < (unsigned)T;
+                acc += (in ? tp[j] : 0.0) * (double)xb[(long)(in ? tt : t) * ldx];
             }
         }
         const long o = ((long)b * rows_per_b_out + t) * ldy + c;
@@ -48,14 +52,26 @@ struct LossArgs {
     float w_mse, w_ce;
 };
 
-// one thread per frame: cross-entropy + argmax over n_phn logits, squared error over n_tv tracks
+// 8 lanes per frame (lane `sub` owns logits sub, sub+8, ... and tracks sub, sub+8): cross-entropy + argmax over n_phn logits,
+// squared error over n_tv tracks.  One thread per frame left 32 blocks of latency-bound serial loops (20 + 34 us fwd / bwd).
+__device__ __forceinline__ float grp8_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+__device__ __forceinline__ float grp8_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
+    return v;
+}
+
 __global__ void loss_fwd_kernel(LossArgs a) {
     __shared__ float red[4][256];
     const long frames = (long)a.B * a.T;
+    const int sub = threadIdx.x & 7;
     float sse = 0.f, ntv = 0.f, ce = 0.f, nph = 0.f;
-    for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < frames; f += (long)gridDim.x * blockDim.x) {
+    // every lane of an 8-lane group takes the same trip count (the group index decides), so the shuffles are convergent
+    for (long f = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; f < frames; f += ((long)gridDim.x * blockDim.x) >> 3) {
         const int b = (int)(f / a.T), t = (int)(f % a.T);
-        for (int c = 0; c < a.n_tv; ++c) {
+        for (int c = sub; c < a.n_tv; c += 8) {
             const float tg = a.tv_tgt[f * a.n_tv + c];
             if (tg != -100.0f) {
                 const float d = a.tv_pred[f * a.n_tv + c] - tg;
@@ -64,19 +80,29 @@ __global__ void loss_fwd_kernel(LossArgs a) {
             }
         }
         const float* lg = a.logits + ((long)b * a.rows_per_b + t) * a.ldl;
-        float mx = lg[0];
-        int am = 0;
-        for (int k = 1; k < a.n_phn; ++k) {
+        float mx = -INFINITY;
+        int am = 0x7fffffff;
+        for (int k = sub; k < a.n_phn; k += 8) {
             const float v = lg[k];
-            if (v > mx) { mx = v; am = k; }
+            if (v > mx || am == 0x7fffffff) { mx = v; am = k; }      // first maximum of this lane's (ascending) classes
         }
-        if (a.pred) a.pred[f] = am;
+        // first maximum over the group: larger value wins, equal values -> smaller index (torch.argmax)
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const float ov = __shfl_xor(mx, o, 64);
+            const int oi = __shfl_xor(am, o, 64);
+            if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+        }
+        if (a.pred && sub == 0) a.pred[f] = am;
         const int64_t tg = a.phn_tgt[f];
-        if (tg != 0) {
+        if (tg != 0) {                                              // uniform within the group
             float se = 0.f;
-            for (int k = 0; k < a.n_phn; ++k) se += __expf(lg[k] - mx);
-            ce += (mx + __logf(se)) - lg[tg];
-            nph += 1.f;
+            for (int k = sub; k < a.n_phn; k += 8) se += __expf(lg[k] - mx);
+            se = grp8_sum(se);
+            if (sub == 0) {
+                ce += (mx + __logf(se)) - lg[tg];
+                nph += 1.f;
+            }
         }
     }
     red[0][threadIdx.x] = sse; red[1][threadIdx.x] = ntv; red[2][threadIdx.x] = ce; red[3][threadIdx.x] = nph;
@@ -89,12 +115,17 @@ __global__ void loss_fwd_kernel(LossArgs a) {
     if (threadIdx.x < 4) a.partials[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
+// one wave: lane l sums the partials of blocks l, l + 64, ... in double, then a fixed-order butterfly
 __global__ void loss_final_kernel(const float* __restrict__ partials, int nblocks, float* __restrict__ scalars, float w_mse,
                                   float w_ce) {
-    if (threadIdx.x != 0) return;
     double s[4] = {0, 0, 0, 0};
-    for (int b = 0; b < nblocks; ++b)
+    for (int b = threadIdx.x; b < nblocks; b += 64)
         for (int k = 0; k < 4; ++k) s[k] += partials[b * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+    if (threadIdx.x != 0) return;
     const float mse = (float)(s[0] / s[1]);        // 0/0 -> nan like F.mse_loss on an empty selection
     const float ce = (w_ce == 0.f && s[3] == 0.0) ? 0.f : (float)(s[2] / s[3]);   // tv-only use (Force_APTAI): no phoneme term
     scalars[0] = w_mse * mse + w_ce * ce;
@@ -104,41 +135,44 @@ __global__ void loss_final_kernel(const float* __restrict__ partials, int nblock
     scalars[4] = (float)s[3];
 }
 
-// d_tv [B][T][n_tv] fp32, d_logits bf16 [B*rows_per_b][ldd] (zero outside the valid region)
+// d_tv [B][T][n_tv] fp32, d_logits bf16 [B*rows_per_b][ldd] (zero outside the valid region); 8 lanes per row
 __global__ void loss_bwd_kernel(LossArgs a, const float* __restrict__ gout, float* __restrict__ d_tv, bf16_t* __restrict__ d_logits,
                                 long ldd) {
     const float g = gout ? gout[0] : 1.f;
     const float k_mse = g * a.w_mse * 2.f / a.scalars[3];
     const float k_ce = g * a.w_ce / a.scalars[4];
     const long rows = (long)a.B * a.rows_per_b;
-    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+    const int sub = threadIdx.x & 7;
+    for (long r = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; r < rows; r += ((long)gridDim.x * blockDim.x) >> 3) {
         const int b = (int)(r / a.rows_per_b), t = (int)(r % a.rows_per_b);
         bf16_t* dl = d_logits + r * ldd;
         if (t >= a.T) {
-            for (int k = 0; k < ldd; ++k) dl[k] = 0;
+            for (int k = sub; k < ldd; k += 8) dl[k] = 0;
             continue;
         }
         const long f = (long)b * a.T + t;
-        for (int c = 0; c < a.n_tv; ++c) {
+        for (int c = sub; c < a.n_tv; c += 8) {
             const float tg = a.tv_tgt[f * a.n_tv + c];
             d_tv[f * a.n_tv + c] = tg != -100.0f ? k_mse * (a.tv_pred[f * a.n_tv + c] - tg) : 0.f;
         }
         const int64_t tg = a.phn_tgt[f];
         if (tg == 0) {
-            for (int k = 0; k < ldd; ++k) dl[k] = 0;
+            for (int k = sub; k < ldd; k += 8) dl[k] = 0;
             continue;
         }
         const float* lg = a.logits + r * a.ldl;
-        float mx = lg[0];
-        for (int k = 1; k < a.n_phn; ++k) mx = fmaxf(mx, lg[k]);
+        float mx = -INFINITY;
+        for (int k = sub; k < a.n_phn; k += 8) mx = fmaxf(mx, lg[k]);
+        mx = grp8_max(mx);
         float se = 0.f;
-        for (int k = 0; k < a.n_phn; ++k) se += __expf(lg[k] - mx);
+        for (int k = sub; k < a.n_phn; k += 8) se += __expf(lg[k] - mx);
+        se = grp8_sum(se);
         const float inv = 1.f / se;
-        for (int k = 0; k < a.n_phn; ++k) {
-            const float p = __expf(lg[k] - mx) * inv;
-            dl[k] = f2bf(k_ce * (p - (k == tg ? 1.f : 0.f)));
+        for (int k = sub; k < ldd; k += 8) {
+            float v = 0.f;
+            if (k < a.n_phn) v = k_ce * (__expf(lg[k] - mx) * inv - (k == tg ? 1.f : 0.f));
+            dl[k] = f2bf(v);
         }
-        for (int k = a.n_phn; k < ldd; ++k) dl[k] = 0;
     }
 }
 
@@ -204,7 +238,7 @@ extern "C" int aptai_aptai_loss_bwd(const float* tv_pred, const float* tv_tgt, c
     APTAI_REQUIRE(scalars && d_tv && d_logits_bf16 && ldd >= n_phn, "aptai_aptai_loss_bwd: bad arguments");
     a.scalars = (float*)scalars;
     const long rows = B * rows_per_b;
-    APTAI_LAUNCH(loss_bwd_kernel, dim3((unsigned)ceil_div(rows, 256)), dim3(256), 0, (hipStream_t)stream, a, grad_out, d_tv,
+    APTAI_LAUNCH(loss_bwd_kernel, dim3((unsigned)ceil_div(rows * 8, 256)), dim3(256), 0, (hipStream_t)stream, a, grad_out, d_tv,
                        (bf16_t*)d_logits_bf16, (long)ldd);
     APTAI_CHECK_LAUNCH("loss_bwd_kernel");
     return APTAI_OK;
