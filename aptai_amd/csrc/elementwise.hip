@@ -355,17 +355,59 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // ---- APTAI head activations: a_tv = tanh(drop(h)), a_ph = leaky_relu(drop(h))   (models/aptai.py:43-55)
+// 8 elements per thread (16-byte loads and stores), one hash per element PAIR (drop_hash_pair: the same mask drop_keep
+// defines), tanh as 1 - 2 / (1 + 2^(2 log2e x)) on the bare v_exp / v_rcp (|err| < 1e-6, the output is bf16).
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -10.f, 10.f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(xc * 2.8853900817779268f));
+}
+__device__ __forceinline__ void keep_scales8(long e0, uint32_t s0, uint32_t s1, uint32_t thr, float sc, float* m) {
+    if (!thr) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) m[r] = 1.f;
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        const uint32_t hsh = drop_hash_pair((uint64_t)(e0 + r), s0, s1);
+        m[r] = (hsh & 0xffffu) >= thr ? sc : 0.f;
+        m[r + 1] = (hsh >> 16) >= thr ? sc : 0.f;
+    }
+}
+__device__ __forceinline__ void unpack8(const u32x4 v, float* x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { x[2 * r] = lo_bf(v[r]); x[2 * r + 1] = hi_bf(v[r]); }
+}
+__device__ __forceinline__ u32x4 pack8f(const float* x) {
+    return (u32x4){pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7])};
+}
+
 __global__ void head_act_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ a_tv, bf16_t* __restrict__ a_ph,
                                     long n, uint32_t s0, uint32_t s1, uint32_t thr_tv, uint32_t thr_ph, float sc_tv,
                                     float sc_ph, const uint32_t* __restrict__ salt) {
     if (thr_tv | thr_ph) apply_salt(salt, s0, s1);
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long n8 = n >> 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        float x[8], mt[8], mp[8], t[8], p[8];
+        unpack8(*(const u32x4*)(h + i * 8), x);
+        keep_scales8(i * 8, s0, s1, thr_tv, sc_tv, mt);
+        keep_scales8(i * 8, s0 ^ 0x5bd1e995u, s1, thr_ph, sc_ph, mp);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float xp = x[r] * mp[r];
+            t[r] = tanh_fast(x[r] * mt[r]);
+            p[r] = xp > 0.f ? xp : 0.01f * xp;
+        }
+        *(u32x4*)(a_tv + i * 8) = pack8f(t);
+        *(u32x4*)(a_ph + i * 8) = pack8f(p);
+    }
+    for (long i = (n8 << 3) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {      // n % 8 tail
         const float x = bf2f(h[i]);
         float xt = x, xp = x;
         if (thr_tv) xt = drop_keep((uint64_t)i, s0, s1, thr_tv) ? x * sc_tv : 0.f;
         if (thr_ph) xp = drop_keep((uint64_t)i, s0 ^ 0x5bd1e995u, s1, thr_ph) ? x * sc_ph : 0.f;
-        a_tv[i] = f2bf(tanhf(xt));
+        a_tv[i] = f2bf(tanh_fast(xt));
         a_ph[i] = f2bf(xp > 0.f ? xp : 0.01f * xp);
     }
 }
@@ -377,14 +419,28 @@ __global__ void head_act_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* 
                                     const uint32_t* __restrict__ salt) {
     if (thr_tv | thr_ph) apply_salt(salt, s0, s1);
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long n8 = n >> 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        float x[8], mt[8], mp[8], gt[8], gp[8], g[8];
+        unpack8(*(const u32x4*)(h + i * 8), x);
+        unpack8(*(const u32x4*)(d_tv + i * 8), gt);
+        unpack8(*(const u32x4*)(d_ph + i * 8), gp);
+        keep_scales8(i * 8, s0, s1, thr_tv, sc_tv, mt);
+        keep_scales8(i * 8, s0 ^ 0x5bd1e995u, s1, thr_ph, sc_ph, mp);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float th = tanh_fast(x[r] * mt[r]);
+            g[r] = gt[r] * (1.f - th * th) * mt[r] + gp[r] * (x[r] * mp[r] > 0.f ? 1.f : 0.01f) * mp[r];
+        }
+        *(u32x4*)(dh + i * 8) = pack8f(g);
+    }
+    for (long i = (n8 << 3) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float x = bf2f(h[i]);
         float xt = x, xp = x, mt = 1.f, mp = 1.f;
         if (thr_tv) { mt = drop_keep((uint64_t)i, s0, s1, thr_tv) ? sc_tv : 0.f; xt = x * mt; }
         if (thr_ph) { mp = drop_keep((uint64_t)i, s0 ^ 0x5bd1e995u, s1, thr_ph) ? sc_ph : 0.f; xp = x * mp; }
-        const float th = tanhf(xt);
-        const float g = bf2f(d_tv[i]) * (1.f - th * th) * mt + bf2f(d_ph[i]) * (xp > 0.f ? 1.f : 0.01f) * mp;
-        dh[i] = f2bf(g);
+        const float th = tanh_fast(xt);
+        dh[i] = f2bf(bf2f(d_tv[i]) * (1.f - th * th) * mt + bf2f(d_ph[i]) * (xp > 0.f ? 1.f : 0.01f) * mp);
     }
 }
 
@@ -393,7 +449,16 @@ __global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict_
                                uint32_t thr, float sc, const uint32_t* __restrict__ salt) {
     apply_salt(salt, s0, s1);
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    const long n8 = n >> 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        float v[8], m[8];
+        unpack8(*(const u32x4*)(x + i * 8), v);
+        keep_scales8(i * 8, s0, s1, thr, sc, m);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= m[r];
+        *(u32x4*)(y + i * 8) = pack8f(v);
+    }
+    for (long i = (n8 << 3) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         y[i] = drop_keep((uint64_t)i, s0, s1, thr) ? f2bf(bf2f(x[i]) * sc) : (bf16_t)0;
 }
 
@@ -557,8 +622,9 @@ extern "C" int aptai_colsum_bf16(const void* x, int64_t ld, float* out, void* wo
 extern "C" int aptai_head_act_fwd(const void* h, void* a_tv, void* a_ph, int64_t n, float p_tv, float p_ph, uint64_t seed,
                                   void* stream) {
     APTAI_REQUIRE(h && a_tv && a_ph && n > 0, "aptai_head_act_fwd: bad arguments");
+    APTAI_REQUIRE((((uintptr_t)h | (uintptr_t)a_tv | (uintptr_t)a_ph) & 15) == 0, "aptai_head_act_fwd: buffers must be 16-byte aligned");
     const uint32_t t1 = drop_thr16(p_tv), t2 = drop_thr16(p_ph);
-    APTAI_LAUNCH(head_act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+    APTAI_LAUNCH(head_act_fwd_kernel, dim3(grid_for(n / 8 + 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                        (bf16_t*)a_tv, (bf16_t*)a_ph, (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t1, t2, drop_scale(t1),
                        drop_scale(t2), aptai_seed_salt());
     APTAI_CHECK_LAUNCH("head_act_fwd_kernel");
@@ -568,8 +634,9 @@ extern "C" int aptai_head_act_fwd(const void* h, void* a_tv, void* a_ph, int64_t
 extern "C" int aptai_head_act_bwd(const void* h, const void* d_tv, const void* d_ph, void* dh, int64_t n, float p_tv,
                                   float p_ph, uint64_t seed, void* stream) {
     APTAI_REQUIRE(h && d_tv && d_ph && dh && n > 0, "aptai_head_act_bwd: bad arguments");
+    APTAI_REQUIRE((((uintptr_t)h | (uintptr_t)d_tv | (uintptr_t)d_ph | (uintptr_t)dh) & 15) == 0, "aptai_head_act_bwd: buffers must be 16-byte aligned");
     const uint32_t t1 = drop_thr16(p_tv), t2 = drop_thr16(p_ph);
-    APTAI_LAUNCH(head_act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+    APTAI_LAUNCH(head_act_bwd_kernel, dim3(grid_for(n / 8 + 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                        (const bf16_t*)d_tv, (const bf16_t*)d_ph, (bf16_t*)dh, (long)n, (uint32_t)seed, (uint32_t)(seed >> 32),
                        t1, t2, drop_scale(t1), drop_scale(t2), aptai_seed_salt());
     APTAI_CHECK_LAUNCH("head_act_bwd_kernel");
@@ -578,8 +645,9 @@ extern "C" int aptai_head_act_bwd(const void* h, const void* d_tv, const void* d
 
 extern "C" int aptai_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream) {
     APTAI_REQUIRE(x && y && n > 0, "aptai_dropout_bf16: bad arguments");
+    APTAI_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "aptai_dropout_bf16: buffers must be 16-byte aligned");
     const uint32_t t = drop_thr16(p);
-    APTAI_LAUNCH(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
+    APTAI_LAUNCH(dropout_kernel, dim3(grid_for(n / 8 + 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
                        (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t, drop_scale(t), aptai_seed_salt());
     APTAI_CHECK_LAUNCH("dropout_kernel");
     return APTAI_OK;
