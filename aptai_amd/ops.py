@@ -296,7 +296,7 @@ def conv_weight_bf16(w: torch.Tensor) -> torch.Tensor:
 def posconv_weight(v, gain, groups, want_dgrad=True):
     _dev(v, gain)
     H, Cg, Kw = v.shape
-    norm_ws = torch.empty(65 * Kw, device=v.device, dtype=torch.float32)      # [Kw] result + [64][Kw] reduction scratch
+    norm_ws = torch.empty(257 * Kw, device=v.device, dtype=torch.float32)     # [Kw] result + [256][Kw] reduction scratch
     norm = norm_ws[:Kw]
     wf = torch.empty((groups, Cg, Kw * Cg), device=v.device, dtype=torch.bfloat16)
     wd = torch.empty_like(wf) if want_dgrad else None

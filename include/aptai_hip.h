@@ -132,7 +132,7 @@ int aptai_adam_multi(const int64_t* table_dev, const int64_t* dyn_dev, int64_t n
 int aptai_conv_weight_to_bf16(const float* src, void* dst, int64_t N, int64_t C, int64_t Kw, void* stream);
 /* positional conv (HF:329-356): weight_norm(dim=2) w = g*v/||v||_(0,1) ; v [H][H/groups][Kw], gain [Kw];
  * w_fwd [groups][Cg][Kw*Cg] (forward), w_dgrad [groups][Cg][Kw*Cg] (flipped taps, in/out swapped; may be null);
- * norm_ws fp32 [65 * Kw]: the first Kw entries receive ||v|| per tap (needed by the weight-norm backward), the rest is
+ * norm_ws fp32 [257 * Kw]: the first Kw entries receive ||v|| per tap (needed by the weight-norm backward), the rest is
  * scratch for the two-stage reduction; Kw must divide 256. */
 int aptai_posconv_weight(const float* v, const float* gain, float* norm_ws, void* w_fwd, void* w_dgrad, int64_t H,
                          int64_t groups, int64_t Kw, void* stream);
