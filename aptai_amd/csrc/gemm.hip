@@ -28,6 +28,13 @@ constexpr int STAGE_BYTES = (BM * BK + BN * BK) * 2;   // 32 KiB
 constexpr int OPER_BYTES = BM * BK * 2;                // 16 KiB per operand tile
 constexpr int EPI_PITCH = BN * 4 + 16;                 // fp32 epilogue tile row pitch (bytes)
 constexpr int SMEM_BYTES = BM * EPI_PITCH > 2 * STAGE_BYTES ? BM * EPI_PITCH : 2 * STAGE_BYTES;
+#ifndef APTAI_GEMM_RING5
+#define APTAI_GEMM_RING5 1
+#endif
+constexpr int RING_HALF_BYTES = (BM + BN) * 32 * 2;    // 16 KiB: 32 k-rows of both operands
+constexpr int SMEM_RING_BYTES = 5 * RING_HALF_BYTES;   // 80 KiB: two blocks per CU use all of the 160 KiB
+static_assert(SMEM_RING_BYTES >= BM * EPI_PITCH, "the epilogue tile must fit the ring");
+template <bool A_KM, bool B_KM> constexpr int smem_for() { return (A_KM && B_KM && APTAI_GEMM_RING5) ? SMEM_RING_BYTES : SMEM_BYTES; }
 
 struct GemmArgs {
     const bf16_t* A; long lda;
@@ -163,6 +170,30 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row_base, 
     }
 }
 
+// The same K-major fragment through inline asm, in two 4-element halves that the caller completes with combine_tr() after its
+// own `s_waitcnt lgkmcnt`.  Why: behind an LDS-DMA the compiler puts `s_waitcnt vmcnt(0)` in front of every
+// __builtin_amdgcn_ds_read_tr16_b64 (it cannot tell which LDS bytes the DMA writes), i.e. right after the staging loads of the
+// NEXT K-tile have been issued - the block then waits for them before it computes the current one and only the other blocks of
+// the CU hide the memory latency.  Plain ds_read_b128 (K-contiguous operands) do not get that wait.  A compiler-inserted
+// lgkmcnt for its own reads stays safe next to these: LDS operations return in order, so it can only over-wait.
+__device__ __forceinline__ uint32_t lds_u32(const char* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void read_frag_tr_asm(const char* lds_tile, int row_base, int ks, int lane, short4v& lo, short4v& hi) {
+    const int g = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3;
+    const int ch = (row_base >> 3) + (p >> 1);
+    const int sub = (p & 1) << 3;
+    const int k_lo = ks * 32 + g * 8 + qq;
+    const int k_hi = k_lo + 4;
+    const uint32_t a0 = lds_u32(lds_tile) + (uint32_t)(k_lo * 256 + ((ch ^ km_swz(k_lo)) << 4) + sub);
+    const uint32_t a1 = lds_u32(lds_tile) + (uint32_t)(k_hi * 256 + ((ch ^ km_swz(k_hi)) << 4) + sub);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+}
+__device__ __forceinline__ bf16x8 combine_tr(const short4v lo, const short4v hi) {
+    return __builtin_bit_cast(bf16x8, (short8v){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+
 // XCD-aware bijective remap: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -189,6 +220,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     constexpr int STAGE_T = A_BYTES_T + BN * BK * 2;
     constexpr int NPASS = BM_T / 16;                    // epilogue passes of 16 rows
     static_assert(BM_T == 128 || (BM_T == 64 && !A_KM), "64-row tiles are built for K-contiguous A only");
+    constexpr bool RING5 = A_KM && B_KM && BM_T == 128 && APTAI_GEMM_RING5;
     const int m0 = tile_m * BM_T, n0 = tile_n * BN;
 
     if (batch >= 0) {
@@ -236,6 +268,111 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
             pb[it] += stepB;
         }
     };
+    if constexpr (RING5) {
+        // Both operands K-major (weight gradients, K = all frames of the batch): the loop is bound by operand delivery, not by
+        // the MFMA pipe (with cache-resident operands the grouped launch runs 33 % faster), and delivery per CU is
+        // bytes-in-flight / latency.  The K-tile is staged as two 32-row half-stages of 16 KiB through a ring of five
+        // (80 KiB per block, two blocks per CU = all of the LDS): three half-stages = 48 KiB per block stay in flight under
+        // the MFMAs instead of one 32-KiB stage, still one barrier per 64 k.  Half h lives in slot h % 5.
+        //   iteration t: wait for halves <= 2t+1 (counted vmcnt: 4 loads per thread and half-stage, only half 2t+2 may be
+        //   outstanding), barrier, issue halves 2t+3 and 2t+4 into the slots of halves 2t-2 and 2t-1 (every wave is past its
+        //   reads of those: it entered the barrier with lgkmcnt(0)), then the MFMAs of halves 2t and 2t+1.
+        constexpr int HALF_T = RING_HALF_BYTES;
+        const bf16_t* ha[2];
+        const bf16_t* hb[2];
+        const long hstepA = 32 * (long)g.lda, hstepB = 32 * (long)g.ldb;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            ha[it] = stage_src<true>(g.A, g.lda, m0, g.M, it, tid) + kt_begin * stepA;
+            hb[it] = stage_src<true>(g.B, g.ldb, n0, g.N, it, tid) + kt_begin * stepB;
+        }
+        auto stage_half = [&](int slot) {
+            char* dst = smem + slot * HALF_T + wave_base_tid * 16;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(ha[it]), LDS_PTR(dst + it * (NTHREADS * 16)), 16, 0, 0);
+                ha[it] += hstepA;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(hb[it]), LDS_PTR(dst + HALF_T / 2 + it * (NTHREADS * 16)), 16, 0, 0);
+                hb[it] += hstepB;
+            }
+        };
+        // per-lane byte offsets of the 16 transposing reads of one half-stage (read_frag<true> with ks = 0): A fragments
+        // 0..3 (lo, hi) in [0, 8 KiB), B fragments in [8 KiB, 16 KiB)
+        uint32_t frag_off[16];
+        {
+            const int gq = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+            const int k_lo = gq * 8 + qq, k_hi = k_lo + 4;
+            const int sub = (pp & 1) << 3;
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                const int is_b = f >> 2, idx = f & 3;
+                const int row_base = is_b ? wn * 64 + idx * 16 : wm * WM + idx * 16;
+                const int ch = (row_base >> 3) + (pp >> 1);
+                frag_off[2 * f] = (uint32_t)(is_b * (HALF_T / 2) + k_lo * 256 + ((ch ^ km_swz(k_lo)) << 4) + sub);
+                frag_off[2 * f + 1] = (uint32_t)(is_b * (HALF_T / 2) + k_hi * 256 + ((ch ^ km_swz(k_hi)) << 4) + sub);
+            }
+        }
+        const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+        const int nh = 2 * nk;
+        if (nh > 0) { stage_half(0); stage_half(1); }
+        if (nh > 2) stage_half(2);
+        int s0 = 0;                                        // slot of half 2t
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int s1 = s0 + 1 >= 5 ? s0 - 4 : s0 + 1, s2 = s0 + 2 >= 5 ? s0 - 3 : s0 + 2, s3 = s0 + 3 >= 5 ? s0 - 2 : s0 + 3,
+                      s4 = s0 + 4 >= 5 ? s0 - 1 : s0 + 4;
+            if (2 * kt + 3 < nh) stage_half(s3);
+            if (2 * kt + 4 < nh) stage_half(s4);
+            if (wave_active) {
+                // The transposing reads go through inline asm: behind an LDS-DMA the compiler puts `s_waitcnt vmcnt(0)` in
+                // front of every ds_read_tr builtin (it cannot tell the slots apart), which would drain the ring at each
+                // K-tile.  So the waits are written here: all 32 reads of the K-tile are issued, the MFMAs of the first half
+                // start once at most 15 are outstanding (LDS reads return in order: the first 17, i.e. the first half's 16,
+                // are back), those of the second half at lgkmcnt(0).  The "+v" operands tie the waits to the fragments.
+                short4v fr[2][16];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const uint32_t base = ring_base + (uint32_t)((hh ? s1 : s0) * HALF_T);
+#pragma unroll
+                    for (int f = 0; f < 16; ++f)
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fr[hh][f]) : "v"(base + frag_off[f]));
+                }
+#define APTAI_TIE8(h, o) "+v"(fr[h][o]), "+v"(fr[h][o + 1]), "+v"(fr[h][o + 2]), "+v"(fr[h][o + 3]), "+v"(fr[h][o + 4]), \
+                         "+v"(fr[h][o + 5]), "+v"(fr[h][o + 6]), "+v"(fr[h][o + 7])
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    if (hh == 0) asm volatile("s_waitcnt lgkmcnt(15)" : APTAI_TIE8(0, 0), APTAI_TIE8(0, 8));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : APTAI_TIE8(1, 0), APTAI_TIE8(1, 8));    // (pinning the first half's MFMAs in front of this wait: 10.22 vs 10.19 ms/step)
+                    bf16x8 af[NI], bfr[4];
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const short4v lo4 = fr[hh][2 * i], hi4 = fr[hh][2 * i + 1];
+                        af[i] = __builtin_bit_cast(bf16x8, (short8v){lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]});
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const short4v lo4 = fr[hh][8 + 2 * j], hi4 = fr[hh][8 + 2 * j + 1];
+                        bfr[j] = __builtin_bit_cast(bf16x8, (short8v){lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]});
+                    }
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+#undef APTAI_TIE8
+            }
+            s0 = s2;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                   // every wave is done with the ring before the epilogue reuses it
+    } else {
     if (nk > 0) stage(smem);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -272,10 +409,35 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     bf16x8 af[NI], bfr[4];
+                    // K-major fragments of the 128-row tiles arrive through read_frag_tr_asm (no compiler vmcnt(0) behind the
+                    // staging loads: NN FFN2 dgrad 58 -> 55 us).  The 64-row tiles keep the builtin: three blocks per CU hide
+                    // the latency already and the compiler's finer lgkmcnt interleave wins there (57 vs 60 us, measured).
+                    constexpr bool ASM_TR = BM_T == 128;
+                    short4v tl[NI + 4], th[NI + 4];
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) af[i] = read_frag<A_KM>(sa, wm * WM + i * 16, ks, lane);
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (B_KM && ASM_TR) read_frag_tr_asm(sb, wn * 64 + j * 16, ks, lane, tl[NI + j], th[NI + j]);
+                        else bfr[j] = read_frag<B_KM>(sb, wn * 64 + j * 16, ks, lane);
+                    }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bfr[j] = read_frag<B_KM>(sb, wn * 64 + j * 16, ks, lane);
+                    for (int i = 0; i < NI; ++i) {
+                        if constexpr (A_KM && ASM_TR) read_frag_tr_asm(sa, wm * WM + i * 16, ks, lane, tl[i], th[i]);
+                        else af[i] = read_frag<A_KM>(sa, wm * WM + i * 16, ks, lane);
+                    }
+                    if constexpr (B_KM && ASM_TR) {
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(tl[NI]), "+v"(tl[NI + 1]), "+v"(tl[NI + 2]), "+v"(tl[NI + 3]), "+v"(th[NI]), "+v"(th[NI + 1]),
+                                       "+v"(th[NI + 2]), "+v"(th[NI + 3]));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bfr[j] = combine_tr(tl[NI + j], th[NI + j]);
+                    }
+                    if constexpr (A_KM && ASM_TR) {
+                        static_assert(!A_KM || NI == 4, "K-major A is built for 128-row tiles");
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(th[0]), "+v"(th[1]), "+v"(th[2]), "+v"(th[3]));
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) af[i] = combine_tr(tl[i], th[i]);
+                    }
 #pragma unroll
                     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -284,6 +446,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
                 }
             }
         }
+    }
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -413,13 +576,14 @@ int launch_gemm_m64(GemmArgs g, int nbatch, int nsplit, hipStream_t stream) {
 template <bool A_KM, bool B_KM, bool OUT_F32>
 int launch_gemm(const GemmArgs& g, int nbatch, int nsplit, hipStream_t stream) {
     auto kern = gemm_kernel<A_KM, B_KM, OUT_F32>;
+    constexpr int smem = smem_for<A_KM, B_KM>();
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     dim3 grid(g.tiles_m * g.tiles_n, nbatch, nsplit);
-    APTAI_LAUNCH(kern, grid, dim3(NTHREADS), SMEM_BYTES, stream, g);
+    APTAI_LAUNCH(kern, grid, dim3(NTHREADS), smem, stream, g);
     APTAI_CHECK_LAUNCH("gemm_kernel");
     return APTAI_OK;
 }
@@ -1109,12 +1273,13 @@ extern "C" int aptai_gemm_bf16_grouped(const aptai_gemm_desc* descs, int n, void
 #define APTAI_GROUPED(AK, BK_, F)                                                                                      \
     do {                                                                                                              \
         auto kern = gemm_grouped_kernel<AK, BK_, F>;                                                                  \
+        constexpr int smem = smem_for<AK, BK_>();                                                                     \
         static bool attr_set = false;                                                                                 \
         if (!attr_set) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);     \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);                  \
             attr_set = true;                                                                                          \
         }                                                                                                             \
-        APTAI_LAUNCH(kern, dim3(total), dim3(NTHREADS), SMEM_BYTES, stream, ga);                                      \
+        APTAI_LAUNCH(kern, dim3(total), dim3(NTHREADS), smem, stream, ga);                                            \
     } while (0)
     if (!akm && !bkm) { if (f32) APTAI_GROUPED(false, false, true); else APTAI_GROUPED(false, false, false); }
     else if (!akm && bkm) { if (f32) APTAI_GROUPED(false, true, true); else APTAI_GROUPED(false, true, false); }
