@@ -231,14 +231,19 @@ struct PosconvWgradArgs {
     int nkt;                                              // K-tiles of 64 frames
 };
 
-__device__ __forceinline__ bf16x8 tr_frag(const char* base, int lane, int ks) {
+// The transposing reads go through inline asm with hand-placed lgkmcnt waits: behind an LDS-DMA the compiler puts
+// `s_waitcnt vmcnt(0)` in front of every ds_read_tr builtin, i.e. it waits for the NEXT K-tile's staging loads before it computes
+// the current one (see read_frag_tr_asm in gemm.hip).
+__device__ __forceinline__ void tr_frag_asm(const char* base, int lane, int ks, short4v& lo, short4v& hi) {
     // 16 rows (the 32 contiguous bytes at `base`, 8-B piece p) x 32 k of a frame-major tile with 96-byte rows
     const int gq = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3;
-    const char* a0 = base + (ks * 32 + gq * 8 + qq) * (CG * 2) + p * 8;
-    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)a0);
-    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(a0 + 4 * CG * 2));
-    short8v r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, r);
+    const uint32_t a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)base +
+                        (uint32_t)((ks * 32 + gq * 8 + qq) * (CG * 2) + p * 8);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a0), "n"(4 * CG * 2));
+}
+__device__ __forceinline__ bf16x8 tr_join(const short4v lo, const short4v hi) {
+    return __builtin_bit_cast(bf16x8, (short8v){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
 
 __global__ __launch_bounds__(256, 3) void posconv_wgrad_kernel(PosconvWgradArgs a) {
@@ -282,13 +287,28 @@ __global__ __launch_bounds__(256, 3) void posconv_wgrad_kernel(PosconvWgradArgs 
         if (kt + 1 < a.nkt) stage(smem + (cur ^ 1) * WG_STAGE);
         const char* sa = smem + cur * WG_STAGE;
         const char* sb = sa + 8192 + wave * 64;            // this wave's 32 columns (2 bytes each)
+        short4v fl[2][5], fh[2][5];                        // fragments 0..2: dU rows, 3..4: this wave's X columns
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tr_frag_asm(sa + i * 32, lane, ks, fl[ks][i], fh[ks][i]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) tr_frag_asm(sb + j * 32, lane, ks, fl[ks][3 + j], fh[ks][3 + j]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // 20 reads issued, in-order return: at most 10 outstanding = the first k-half is back
+            if (ks == 0)
+                asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(fl[0][0]), "+v"(fl[0][1]), "+v"(fl[0][2]), "+v"(fl[0][3]), "+v"(fl[0][4]),
+                                                       "+v"(fh[0][0]), "+v"(fh[0][1]), "+v"(fh[0][2]), "+v"(fh[0][3]), "+v"(fh[0][4]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fl[1][0]), "+v"(fl[1][1]), "+v"(fl[1][2]), "+v"(fl[1][3]), "+v"(fl[1][4]),
+                                                      "+v"(fh[1][0]), "+v"(fh[1][1]), "+v"(fh[1][2]), "+v"(fh[1][3]), "+v"(fh[1][4]));
             bf16x8 af[3], bfr[2];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) af[i] = tr_frag(sa + i * 32, lane, ks);
+            for (int i = 0; i < 3; ++i) af[i] = tr_join(fl[ks][i], fh[ks][i]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = tr_frag(sb + j * 32, lane, ks);
+            for (int j = 0; j < 2; ++j) bfr[j] = tr_join(fl[ks][3 + j], fh[ks][3 + j]);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
