@@ -96,20 +96,23 @@ __global__ __launch_bounds__(256) void posconv_norm_partial_kernel(const float* 
         partial[(long)blockIdx.x * Kw + threadIdx.x] = t;
     }
 }
-// one block of 256 threads: thread (grp, kk) adds the partials of blocks grp, grp + 256/Kw, ... for tap kk (coalesced over kk),
-// then the first Kw threads add the 256/Kw group sums in a fixed order
-__global__ __launch_bounds__(256) void posconv_norm_final_kernel(const float* __restrict__ partial, float* __restrict__ norm, int Kw) {
-    __shared__ float red[256];
-    const int groups = 256 / Kw, grp = threadIdx.x / Kw, kk = threadIdx.x % Kw;
+// sum_r partial[r][kk] for one tap kk per block: 256 threads take rows r = t, t + 256, ... (independent loads), then a
+// fixed-order LDS tree.  (A thread per tap walking all rows serially is a chain of dependent L2 round trips: 178 us for 768 rows.)
+__device__ __forceinline__ float tap_total(const float* __restrict__ partial, int R, int Kw, int kk, float* red) {
     float s = 0.f;
-    for (int b = grp; b < PCN_BLOCKS; b += groups) s += partial[(long)b * Kw + kk];
+    for (int r = threadIdx.x; r < R; r += 256) s += partial[(long)r * Kw + kk];
     red[threadIdx.x] = s;
     __syncthreads();
-    if ((int)threadIdx.x < Kw) {
-        float t = 0.f;
-        for (int g = 0; g < groups; ++g) t += red[g * Kw + threadIdx.x];
-        norm[threadIdx.x] = sqrtf(t);
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
     }
+    return red[0];
+}
+__global__ __launch_bounds__(256) void posconv_norm_final_kernel(const float* __restrict__ partial, float* __restrict__ norm, int Kw) {
+    __shared__ float red[256];
+    const float t = tap_total(partial, PCN_BLOCKS, Kw, blockIdx.x, red);
+    if (threadIdx.x == 0) norm[blockIdx.x] = sqrtf(t);
 }
 
 // w = g*v/norm ->  fwd layout  Wf[grp][n][kk*Cg + c]            = w[grp*Cg+n][c][kk]
@@ -161,14 +164,15 @@ __global__ __launch_bounds__(256) void posconv_wn_dot_kernel(const float* __rest
         partial[(long)o * Kw + threadIdx.x] = t;
     }
 }
-__global__ void posconv_wn_final_kernel(const float* __restrict__ partial, const float* __restrict__ norm, float* __restrict__ dot,
-                                        float* __restrict__ dgain, int H, int Kw) {
-    const int kk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (kk >= Kw) return;
-    float s = 0.f;
-    for (int o = 0; o < H; ++o) s += partial[(long)o * Kw + kk];
-    dot[kk] = s;
-    dgain[kk] = s / norm[kk];
+__global__ __launch_bounds__(256) void posconv_wn_final_kernel(const float* __restrict__ partial, const float* __restrict__ norm,
+                                                               float* __restrict__ dot, float* __restrict__ dgain, int H, int Kw) {
+    __shared__ float red[256];
+    const int kk = blockIdx.x;
+    const float s = tap_total(partial, H, Kw, kk, red);
+    if (threadIdx.x == 0) {
+        dot[kk] = s;
+        dgain[kk] = s / norm[kk];
+    }
 }
 __global__ __launch_bounds__(256) void posconv_wn_apply_kernel(const float* __restrict__ dwf, const float* __restrict__ v,
                                                                const float* __restrict__ gain, const float* __restrict__ norm,
@@ -529,7 +533,7 @@ extern "C" int aptai_posconv_weight(const float* v, const float* gain, float* no
     float* partial = norm_ws + Kw;                      // [256][Kw] scratch behind the result
     APTAI_LAUNCH(posconv_norm_partial_kernel, dim3(PCN_BLOCKS), dim3(256), 0, (hipStream_t)stream, v, partial, nel, (int)Kw);
     APTAI_CHECK_LAUNCH("posconv_norm_partial_kernel");
-    APTAI_LAUNCH(posconv_norm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, norm_ws, (int)Kw);
+    APTAI_LAUNCH(posconv_norm_final_kernel, dim3((unsigned)Kw), dim3(256), 0, (hipStream_t)stream, (const float*)partial, norm_ws, (int)Kw);
     APTAI_CHECK_LAUNCH("posconv_norm_final_kernel");
     const size_t slab_bytes = (size_t)Cg * (Kw + 1) * 4;
     APTAI_REQUIRE(slab_bytes <= 64 * 1024, "aptai_posconv_weight: Cg*Kw slab of %ld bytes exceeds the LDS budget", (long)slab_bytes);
@@ -562,7 +566,7 @@ extern "C" int aptai_posconv_weight_bwd(const float* dw_fwd, const float* v, con
     hipStream_t st = (hipStream_t)stream;
     APTAI_LAUNCH(posconv_wn_dot_kernel, dim3((unsigned)H), dim3(256), slab_bytes, st, dw_fwd, v, partial, Cg, (int)Kw);
     APTAI_CHECK_LAUNCH("posconv_wn_dot_kernel");
-    APTAI_LAUNCH(posconv_wn_final_kernel, dim3((unsigned)ceil_div(Kw, 128)), dim3(128), 0, st, (const float*)partial, norm, dot, dgain, (int)H, (int)Kw);
+    APTAI_LAUNCH(posconv_wn_final_kernel, dim3((unsigned)Kw), dim3(256), 0, st, (const float*)partial, norm, dot, dgain, (int)H, (int)Kw);
     APTAI_CHECK_LAUNCH("posconv_wn_final_kernel");
     APTAI_LAUNCH(posconv_wn_apply_kernel, dim3((unsigned)H), dim3(256), slab_bytes, st, dw_fwd, v, gain, norm, (const float*)dot, dv, Cg, (int)Kw);
     APTAI_CHECK_LAUNCH("posconv_wn_apply_kernel");
