@@ -31,6 +31,9 @@ constexpr int SMEM_BYTES = BM * EPI_PITCH > 2 * STAGE_BYTES ? BM * EPI_PITCH : 2
 #ifndef APTAI_GEMM_RING5
 #define APTAI_GEMM_RING5 1
 #endif
+#ifndef APTAI_GEMM_M64_ASM
+#define APTAI_GEMM_M64_ASM 1
+#endif
 constexpr int RING_HALF_BYTES = (BM + BN) * 32 * 2;    // 16 KiB: 32 k-rows of both operands
 constexpr int SMEM_RING_BYTES = 5 * RING_HALF_BYTES;   // 80 KiB: two blocks per CU use all of the 160 KiB
 static_assert(SMEM_RING_BYTES >= BM * EPI_PITCH, "the epilogue tile must fit the ring");
@@ -405,13 +408,44 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+            } else if constexpr (BM_T == 64 && !A_KM && B_KM && APTAI_GEMM_M64_ASM) {
+                // 64-row NN tiles (the dgrads): every LDS read of the K-tile through inline asm, issued up front in the order
+                // B(k-half 0) x8, A(0) x2, B(1) x8, A(1) x2; LDS reads return in order, so lgkmcnt(10) = the first half is back
+                short4v bl[2][4], bh[2][4];
+                u32x4 aa[2][2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) read_frag_tr_asm(sb, wn * 64 + j * 16, ks, lane, bl[ks][j], bh[ks][j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = wm * WM + i * 16 + (lane & 15), q = ks * 4 + (lane >> 4);
+                        const uint32_t addr = lds_u32(sa) + (uint32_t)(row * 128 + ((q ^ (row & 7)) << 4));
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(aa[ks][i]) : "v"(addr));
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (ks == 0)
+                        asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[0][2]), "+v"(bl[0][3]), "+v"(bh[0][0]),
+                                                               "+v"(bh[0][1]), "+v"(bh[0][2]), "+v"(bh[0][3]), "+v"(aa[0][0]), "+v"(aa[0][1]));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bl[1][0]), "+v"(bl[1][1]), "+v"(bl[1][2]), "+v"(bl[1][3]), "+v"(bh[1][0]),
+                                                              "+v"(bh[1][1]), "+v"(bh[1][2]), "+v"(bh[1][3]), "+v"(aa[1][0]), "+v"(aa[1][1]));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(combine_tr(bl[ks][j], bh[ks][j]),
+                                                                                __builtin_bit_cast(bf16x8, aa[ks][i]), acc[i][j], 0, 0, 0);
+                }
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     bf16x8 af[NI], bfr[4];
                     // K-major fragments of the 128-row tiles arrive through read_frag_tr_asm (no compiler vmcnt(0) behind the
-                    // staging loads: NN FFN2 dgrad 58 -> 55 us).  The 64-row tiles keep the builtin: three blocks per CU hide
-                    // the latency already and the compiler's finer lgkmcnt interleave wins there (57 vs 60 us, measured).
+                    // staging loads: NN FFN2 dgrad 58 -> 55 us).  The 64-row NN tiles have their own all-asm branch above; with
+                    // only the B reads in asm and one lgkmcnt(0) per k-half they lost to the builtin (57 vs 60 us).
                     constexpr bool ASM_TR = BM_T == 128;
                     short4v tl[NI + 4], th[NI + 4];
 #pragma unroll
