@@ -197,6 +197,22 @@ __device__ __forceinline__ bf16x8 combine_tr(const short4v lo, const short4v hi)
     return __builtin_bit_cast(bf16x8, (short8v){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
 
+// one MFMA operand fragment: K-contiguous -> plain ds_read_b128 (compiler-scheduled); K-major -> the asm pair above, valid only
+// after the caller's own `s_waitcnt lgkmcnt`
+template <bool KM>
+struct Frag {
+    bf16x8 v;
+    short4v lo, hi;
+    __device__ __forceinline__ void read(const char* lds_tile, int row_base, int ks, int lane) {
+        if constexpr (KM) read_frag_tr_asm(lds_tile, row_base, ks, lane, lo, hi);
+        else v = read_frag<false>(lds_tile, row_base, ks, lane);
+    }
+    __device__ __forceinline__ bf16x8 get() const {
+        if constexpr (KM) return combine_tr(lo, hi);
+        else return v;
+    }
+};
+
 // XCD-aware bijective remap: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -735,7 +751,11 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
 
-    bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+    // K-major fragments come through inline asm (Frag<true>): the compiler would put `s_waitcnt vmcnt(0)` in front of the
+    // ds_read_tr builtins and drain the four half-tiles this schedule keeps in flight.  They are complete at the explicit
+    // lgkmcnt(0) in front of each MFMA section (the sched_barrier behind it keeps the MFMAs below).
+    Frag<A_KM> af[4][2];
+    Frag<B_KM> b0f[2][2], b1f[2][2];
     for (int t = 0; t < nk; ++t) {
         const char* buf = smem + (t & 1) * T2_BUF_BYTES;
         const char* sA0 = buf, *sA1 = buf + T2_HALF_BYTES, *sB0 = buf + 2 * T2_HALF_BYTES, *sB1 = buf + 3 * T2_HALF_BYTES;
@@ -746,22 +766,22 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) b0f[j][ks] = read_frag<B_KM>(sB0, wc * 32 + j * 16, ks, lane);
+                    for (int ks = 0; ks < 2; ++ks) b0f[j][ks].read(sB0, wc * 32 + j * 16, ks, lane);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) af[i][ks] = read_frag<A_KM>(sA0, wr * 64 + i * 16, ks, lane);
+                    for (int ks = 0; ks < 2; ++ks) af[i][ks].read(sA0, wr * 64 + i * 16, ks, lane);
             } else if (p == 1) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) b1f[j][ks] = read_frag<B_KM>(sB1, wc * 32 + j * 16, ks, lane);
+                    for (int ks = 0; ks < 2; ++ks) b1f[j][ks].read(sB1, wc * 32 + j * 16, ks, lane);
             } else if (p == 2) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) af[i][ks] = read_frag<A_KM>(sA1, wr * 64 + i * 16, ks, lane);
+                    for (int ks = 0; ks < 2; ++ks) af[i][ks].read(sA1, wr * 64 + i * 16, ks, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
             const int G = 4 * t + p;
@@ -788,9 +808,9 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const bf16x8 bfrag = (QN[p] == 0) ? b0f[j][ks] : b1f[j][ks];
+                        const bf16x8 bfrag = (QN[p] == 0) ? b0f[j][ks].get() : b1f[j][ks].get();
                         acc[QM[p]][QN[p]][i][j] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag, af[i][ks], acc[QM[p]][QN[p]][i][j], 0, 0, 0);
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag, af[i][ks].get(), acc[QM[p]][QN[p]][i][j], 0, 0, 0);
                     }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);

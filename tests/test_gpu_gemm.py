@@ -39,7 +39,7 @@ class _TileOps:
         return self._ops.gemm(*a, **kw)
 
 
-@pytest.fixture(scope="module", params=[0, 64, 128, 192], ids=["auto", "t64", "t128", "t192"])
+@pytest.fixture(scope="module", params=[0, 64, 128, 192, 256], ids=["auto", "t64", "t128", "t192", "t256"])
 def ops(request):
     from aptai_amd import ops
     return _TileOps(ops, request.param)
