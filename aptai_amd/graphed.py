@@ -31,6 +31,11 @@ from .aptai import APTAI, heads_bwd, heads_fwd
 from .wav2vec2 import _FinalLNImpl, _FrontImpl, _LayerImpl, _seed
 
 
+# thread-local capture: under data parallelism the process group's watchdog thread polls its events while this thread captures,
+# and in the default "global" mode a call from ANY thread can invalidate the capture
+_CAPTURE_MODE = "thread_local"
+
+
 class GraphedAPTAIStep:
     def __init__(self, model: APTAI, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], reducer=None):
         assert model.training, "call model.train() first"
@@ -152,7 +157,7 @@ class GraphedAPTAIStep:
         w._cache_mode = "build"
         torch.cuda.synchronize()
         self.g_prep = mk()
-        with torch.cuda.graph(self.g_prep, pool=pool):
+        with torch.cuda.graph(self.g_prep, pool=pool, capture_error_mode=_CAPTURE_MODE):
             w._conv_weights()
             if not getattr(self.opt, "publishes_copies", False):     # else the optimiser kernel refreshes the copies itself
                 w._refresh_layer_copies(force=True)
@@ -173,7 +178,7 @@ class GraphedAPTAIStep:
                         pc.parametrizations.weight.original0, pc.parametrizations.weight.original1, pc.bias,
                         w.encoder.layer_norm.weight, w.encoder.layer_norm.bias]
         self.g_front = mk()
-        with torch.cuda.graph(self.g_front, pool=pool):
+        with torch.cuda.graph(self.g_front, pool=pool, capture_error_mode=_CAPTURE_MODE):
             if embed is not None and cfg.apply_spec_augment and cfg.mask_time_prob > 0:
                 ops.spec_augment_mask(self.lens_i32, g.B, g.T, cfg.mask_time_prob, cfg.mask_time_length, cfg.mask_time_min_masks,
                                       _seed(seed, 77), out=self.spec)        # fresh spans on every replay (salted seed)
@@ -188,7 +193,7 @@ class GraphedAPTAIStep:
             impl = _LayerImpl(cfg, g, self.lens_i32, wt, True, _seed(seed, 100 + i))
             params = [layer.layer_norm.weight, layer.layer_norm.bias, layer.final_layer_norm.weight, layer.final_layer_norm.bias] + lin
             gr = mk()
-            with torch.cuda.graph(gr, pool=pool):
+            with torch.cuda.graph(gr, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 (y,), s = impl.fwd(self.X[i], params, True)
             self.impl.append(impl); self.s_layer.append(s); self.g_fwd.append(gr); self.lparams.append(params)
             self.X.append(y)
@@ -203,7 +208,7 @@ class GraphedAPTAIStep:
             self.st_heads.norm_scalars = self.loss_norm.buffer(self.dev)
         self.fin = _FinalLNImpl(cfg, g) if cfg.do_stable_layer_norm else None
         self.g_tail = mk()
-        with torch.cuda.graph(self.g_tail, pool=pool):
+        with torch.cuda.graph(self.g_tail, pool=pool, capture_error_mode=_CAPTURE_MODE):
             hl = self.X[L]
             if self.fin is not None:
                 (hl,), s_fin = self.fin.fwd(hl, [w.encoder.layer_norm.weight, w.encoder.layer_norm.bias], True)
@@ -225,7 +230,7 @@ class GraphedAPTAIStep:
         self.layer_grads = [None] * L
         for i in range(L - 1, -1, -1):
             gr = mk()
-            with torch.cuda.graph(gr, pool=pool):
+            with torch.cuda.graph(gr, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 dx, pg = self.impl[i].bwd(self.s_layer[i], (self.dX[i + 1],), True)
             self.g_bwd[i] = gr
             self.dX[i] = dx
@@ -233,7 +238,7 @@ class GraphedAPTAIStep:
 
         # -- front backward
         self.g_front_bwd = mk()
-        with torch.cuda.graph(self.g_front_bwd, pool=pool):
+        with torch.cuda.graph(self.g_front_bwd, pool=pool, capture_error_mode=_CAPTURE_MODE):
             _, fg = self.front.bwd(self.s_front, (self.dX[0],), False)
         for p, gt in zip(self.fparams, fg):
             if p is not None and gt is not None:
