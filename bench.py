@@ -210,6 +210,29 @@ def main():
         model.dp_loss_norm = GlobalLossNorm()
     batch = synth_batch(cfg, B, S, args.n_tv, rank, device)
 
+    runner = None
+    if not args.eager:
+        from aptai_amd.graphed import GraphedAPTAIStep
+        try:
+            if reducer is not None:
+                reducer.remove()             # gradients are reduced explicitly after the captured backward
+            runner = GraphedAPTAIStep(model, opt, batch, reducer=reducer)
+            step = runner.step
+            if args.host_batch:              # the collate_fn's view of the boundary: host tensors in, H2D inside the step
+                host = {k: v.cpu().pin_memory() for k, v in batch.items()}
+                step = lambda: runner.step(host)
+        except Exception as e:               # noqa: BLE001 - multi-rank only: same kernels through the eager loop, and say so
+            if world == 1:
+                raise
+            print(f"[bench] rank {rank}: hipGraph capture failed ({e!r}); running the eager loop", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            runner = None
+            args.eager = True
+            from aptai_amd import _lib                   # what GraphedAPTAIStep.close() would have reset
+            _lib.call("aptai_set_seed_salt", None)
+            model.wav2vec2._cache_mode = None
+            model.wav2vec2._cache.clear()
+            reducer = GradBucketReducer(params, bucket_mb=48.0, comm_dtype=torch.bfloat16)
     if args.eager:
         def step():
             opt.zero_grad(set_to_none=True)
@@ -219,15 +242,6 @@ def main():
                 reducer.finish()
             opt.step()
             return out
-    else:
-        from aptai_amd.graphed import GraphedAPTAIStep
-        if reducer is not None:
-            reducer.remove()                 # gradients are reduced explicitly after the captured backward
-        runner = GraphedAPTAIStep(model, opt, batch, reducer=reducer)
-        step = runner.step
-        if args.host_batch:                  # the collate_fn's view of the boundary: host tensors in, H2D inside the step
-            host = {k: v.cpu().pin_memory() for k, v in batch.items()}
-            step = lambda: runner.step(host)
 
     for _ in range(args.warmup):
         step()
