@@ -216,6 +216,8 @@ def main():
         try:
             if reducer is not None:
                 reducer.remove()             # gradients are reduced explicitly after the captured backward
+            if os.environ.get("APTAI_BENCH_FAIL_CAPTURE"):      # rehearsal of the fallback below
+                raise RuntimeError("APTAI_BENCH_FAIL_CAPTURE is set")
             runner = GraphedAPTAIStep(model, opt, batch, reducer=reducer)
             step = runner.step
             if args.host_batch:              # the collate_fn's view of the boundary: host tensors in, H2D inside the step
