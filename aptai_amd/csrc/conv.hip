@@ -174,18 +174,40 @@ __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args a) {
     }
     const float* xb = a.audio + (long)b * a.S;
     bf16_t* ob = a.out + (long)b * a.T_alloc * C0;
-    for (int t = blockIdx.x * 4 + wave; t < a.T_alloc; t += gridDim.x * 4) {
+    // the 10 samples of the NEXT frame are loaded before the current one is computed: without the prefetch every frame
+    // exposes one global-load latency to its wave (the loop body is only ~170 VALU instructions)
+    const int tstep = gridDim.x * 4;
+    int t = blockIdx.x * 4 + wave;
+    float xs[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) xs[k] = 0.f;
+    if (t < a.T_real) {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) xs[k] = xb[(long)t * STRIDE + k];
+    }
+    for (; t < a.T_alloc; t += tstep) {
+        float xn[KW];
+        const int tn = t + tstep;
+        const bool has_next = tn < a.T_real;
+        const float* xp = xb + (long)(has_next ? tn : 0) * STRIDE;       // clamped: the load is always in bounds
+#pragma unroll
+        for (int k = 0; k < KW; ++k) xn[k] = xp[k];
         float o[8];
         if (t < a.T_real) {
-            float v[8];
-            conv_frame(xb + (long)t * STRIDE, w, bias, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = gelu_fast(fmaf(v[j], sc[j], sh[j]));
+            for (int j = 0; j < 8; ++j) {
+                float acc = bias[j];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) acc = fmaf(xs[k], w[j][k], acc);
+                o[j] = gelu_fast(fmaf(acc, sc[j], sh[j]));
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = 0.f;
         }
         store8(ob + (long)t * C0 + lane * 8, o);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) xs[k] = xn[k];
     }
 }
 
