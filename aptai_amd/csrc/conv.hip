@@ -62,11 +62,32 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args a) {
     for (int j = 0; j < 8; ++j) { gm[j] = a.gamma[lane * 8 + j]; bt[j] = a.beta[lane * 8 + j]; }
     const float* xb = a.audio + (long)b * a.S;
     bf16_t* ob = a.out + (long)b * a.T_alloc * C0;
-    for (int t = blockIdx.x * 4 + wave; t < a.T_alloc; t += gridDim.x * 4) {
+    // next frame's samples prefetched under the current frame's arithmetic (see conv0_group_kernel)
+    const int tstep = gridDim.x * 4;
+    int t = blockIdx.x * 4 + wave;
+    float xs[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) xs[k] = 0.f;
+    if (t < a.T_real) {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) xs[k] = xb[(long)t * STRIDE + k];
+    }
+    for (; t < a.T_alloc; t += tstep) {
+        float xn[KW];
+        const int tn = t + tstep;
+        const float* xp = xb + (long)(tn < a.T_real ? tn : 0) * STRIDE;      // clamped: always in bounds
+#pragma unroll
+        for (int k = 0; k < KW; ++k) xn[k] = xp[k];
         float o[8];
         if (t < a.T_real) {
             float v[8];
-            conv_frame(xb + (long)t * STRIDE, w, bias, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float acc = bias[j];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) acc = fmaf(xs[k], w[j][k], acc);
+                v[j] = acc;
+            }
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
@@ -82,6 +103,8 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args a) {
             for (int j = 0; j < 8; ++j) o[j] = 0.f;
         }
         store8(ob + (long)t * C0 + lane * 8, o);
+#pragma unroll
+        for (int k = 0; k < KW; ++k) xs[k] = xn[k];
     }
 }
 
