@@ -1250,7 +1250,12 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         const long t128 = ceil_div(d->M, BM) * ceil_div(d->N, BN) * nbatch * nsplit;
         const double e256 = (double)t256 / (double)(ceil_div(t256, 256) * 256);
         const double e128 = (double)t128 / (double)(ceil_div(t128, 512) * 512);
-        tile = (d->M >= 256 && d->N >= 256 && 1.25 * e256 > e128) ? 256 : 128;
+        static double f256 = -1.0;
+        if (f256 < 0) {
+            const char* e = getenv("APTAI_GEMM_F256");      // A/B knob for the 256-tile advantage factor (default 1.25)
+            f256 = e ? atof(e) : 1.25;
+        }
+        tile = (d->M >= 256 && d->N >= 256 && f256 * e256 > e128) ? 256 : 128;
         // 128x192 tiles (one block per CU): measured faster than the 128-tile kernel only where the whole K-contiguous GEMM
         // is ONE round of full tiles (8192 x 768: 16.9 vs 19.7 us at K = 768, 43.6 vs 51.2 us at K = 3072)
         const long t192 = ceil_div(d->M, T3_BM) * ceil_div(d->N, T3_BN) * nbatch * nsplit;
