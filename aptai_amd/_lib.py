@@ -75,7 +75,7 @@ ARGTYPES = {
     "aptai_ctc_bwd": [_P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _F, _P, _I64, _I, _P],
     "aptai_ctc_workspace_bytes": [_I64, _I64, _I64],
     "aptai_device_check": [ctypes.c_char_p, _I],
-    "aptai_set_seed_salt": [_P],
+    "aptai_set_seed_salt": [_P, _P],
 }
 
 

@@ -10,8 +10,10 @@ drop-in.  Nothing here imports ``transformers``.
 from __future__ import annotations
 
 import dataclasses
+import io
 import json
 import os
+import pickle
 from typing import Any, Tuple
 
 
@@ -119,3 +121,53 @@ class W2V2Config:
                  feat_extract_norm="layer", conv_bias=True, do_stable_layer_norm=True)
         d.update(kw)
         return cls(**d)
+
+
+# ---------------------------------------------------------------------------------------- model_cfg.pkl
+class _AttrBag:
+    """Stand-in for a pickled configuration OBJECT (the reference pickles a ``transformers.Wav2Vec2Config`` inside
+    ``get_config()``, train/train_phoneme_recognizer.py:472-473): receives the instance ``__dict__`` and nothing else."""
+
+    def __setstate__(self, state):
+        if isinstance(state, tuple) and len(state) == 2:          # (dict, slots)
+            state = {**(state[0] or {}), **(state[1] or {})}
+        self.__dict__.update(state or {})
+
+
+_SAFE_GLOBALS = {
+    ("builtins", n): getattr(__import__("builtins"), n)
+    for n in ("dict", "list", "tuple", "set", "frozenset", "str", "int", "float", "bool", "bytes", "complex", "object")
+}
+_SAFE_GLOBALS[("collections", "OrderedDict")] = __import__("collections").OrderedDict
+
+
+class _ConfigUnpickler(pickle.Unpickler):
+    """Unpickler for ``model_cfg.pkl``: containers of plain values, ``torch.device``, and configuration objects, which are
+    rebuilt as attribute bags WITHOUT importing or calling their class.  Every other global raises - a checkpoint directory
+    cannot make this process run code."""
+
+    def find_class(self, module, name):
+        if (module, name) in _SAFE_GLOBALS:
+            return _SAFE_GLOBALS[(module, name)]
+        if (module, name) == ("copyreg", "_reconstructor"):
+            return lambda cls, base, state: cls.__new__(cls)
+        if (module, name) == ("torch", "device"):
+            import torch
+            return torch.device
+        if name.endswith("Config") and (module.startswith("transformers.") or module.startswith("aptai_amd.")):
+            if module.startswith("aptai_amd.") and name == "W2V2Config":
+                return W2V2Config
+            return _AttrBag
+        if (module, name) == ("argparse", "Namespace"):
+            return _AttrBag
+        raise pickle.UnpicklingError(f"model_cfg.pkl: global {module}.{name} is not allowed (plain values, torch.device and "
+                                     f"configuration objects only)")
+
+
+def load_model_cfg(path: str) -> dict:
+    """The ``get_config()`` dict the training scripts pickle next to ``pytorch_model.bin`` (models/force_aptai.py:61-64)."""
+    with open(path, "rb") as f:
+        obj = _ConfigUnpickler(io.BytesIO(f.read())).load()
+    if not isinstance(obj, dict):
+        raise pickle.UnpicklingError(f"{path}: expected the get_config() dict, found {type(obj).__name__}")
+    return obj

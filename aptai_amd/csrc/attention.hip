@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens, int64_t B, int64_t Tp, int64_t H,
-              int64_t heads, float scale, float dropout_p, uint64_t seed) {
+              int64_t heads, float scale, float dropout_p, uint64_t seed, const void* stream) {
     APTAI_REQUIRE(qkv && lens, "%s: null pointer", who);
     APTAI_REQUIRE(B > 0 && Tp > 0 && Tp % 128 == 0, "%s: frames per utterance (%ld) must be a positive multiple of 128", who, (long)Tp);
     APTAI_REQUIRE(heads > 0 && H == heads * HD, "%s: head_dim must be 64 (H=%ld heads=%ld)", who, (long)H, (long)heads);
@@ -486,7 +486,7 @@ int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens
     a.scale = scale; a.c = scale * LOG2E;
     a.thr16 = drop_thr16(dropout_p); a.dscale = drop_scale(a.thr16);
     a.seed0 = (uint32_t)seed; a.seed1 = (uint32_t)(seed >> 32);
-    a.salt = aptai_seed_salt();
+    a.salt = aptai_seed_salt(stream);
     return APTAI_OK;
 }
 
@@ -496,7 +496,7 @@ extern "C" int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* c
                                    int64_t Tp, int64_t H, int64_t heads, float scale, float dropout_p, uint64_t seed,
                                    void* stream_) {
     AttnArgs a;
-    int rc = fill_args(a, "aptai_attention_fwd", qkv, lens, B, Tp, H, heads, scale, dropout_p, seed);
+    int rc = fill_args(a, "aptai_attention_fwd", qkv, lens, B, Tp, H, heads, scale, dropout_p, seed, stream_);
     if (rc) return rc;
     APTAI_REQUIRE(ctx != nullptr, "aptai_attention_fwd: null ctx");
     a.ctx = (bf16_t*)ctx; a.lse2 = lse2; a.o32 = ctx_f32;
@@ -511,7 +511,7 @@ extern "C" int aptai_attention_bwd(const void* qkv, const int32_t* lens, const v
                                    int64_t heads, float scale, float dropout_p, uint64_t seed, int dctx_zero_beyond_len, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AttnArgs a;
-    int rc = fill_args(a, "aptai_attention_bwd", qkv, lens, B, Tp, H, heads, scale, dropout_p, seed);
+    int rc = fill_args(a, "aptai_attention_bwd", qkv, lens, B, Tp, H, heads, scale, dropout_p, seed, stream_);
     if (rc) return rc;
     APTAI_REQUIRE(ctx && dctx && lse2 && delta_ws && dqkv, "aptai_attention_bwd: null pointer");
     a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.lse2 = (float*)lse2; a.delta = delta_ws; a.o32 = (float*)ctx_f32; a.dqkv = (bf16_t*)dqkv;

@@ -549,7 +549,7 @@ extern "C" int aptai_spec_augment_mask(const int32_t* frame_lens, void* mask_u8,
     APTAI_REQUIRE(mask_length >= 1 && mask_length <= T, "aptai_spec_augment_mask: mask_length=%ld must lie in [1, T=%ld]", (long)mask_length, (long)T);
     APTAI_REQUIRE(mask_prob >= 0.f && mask_prob <= 1.f && min_masks >= 0, "aptai_spec_augment_mask: bad mask_prob / min_masks");
     APTAI_LAUNCH(spec_mask_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, frame_lens, (uint8_t*)mask_u8, (int)T, mask_prob,
-                 (int)mask_length, (int)min_masks, (uint32_t)seed, (uint32_t)(seed >> 32), aptai_seed_salt());
+                 (int)mask_length, (int)min_masks, (uint32_t)seed, (uint32_t)(seed >> 32), aptai_seed_salt(stream));
     APTAI_CHECK_LAUNCH("spec_mask_kernel");
     return APTAI_OK;
 }
@@ -637,7 +637,7 @@ extern "C" int aptai_head_act_fwd(const void* h, void* a_tv, void* a_ph, int64_t
     const uint32_t t1 = drop_thr16(p_tv), t2 = drop_thr16(p_ph);
     APTAI_LAUNCH(head_act_fwd_kernel, dim3(grid_for(n / 8 + 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                        (bf16_t*)a_tv, (bf16_t*)a_ph, (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t1, t2, drop_scale(t1),
-                       drop_scale(t2), aptai_seed_salt());
+                       drop_scale(t2), aptai_seed_salt(stream));
     APTAI_CHECK_LAUNCH("head_act_fwd_kernel");
     return APTAI_OK;
 }
@@ -649,7 +649,7 @@ extern "C" int aptai_head_act_bwd(const void* h, const void* d_tv, const void* d
     const uint32_t t1 = drop_thr16(p_tv), t2 = drop_thr16(p_ph);
     APTAI_LAUNCH(head_act_bwd_kernel, dim3(grid_for(n / 8 + 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
                        (const bf16_t*)d_tv, (const bf16_t*)d_ph, (bf16_t*)dh, (long)n, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       t1, t2, drop_scale(t1), drop_scale(t2), aptai_seed_salt());
+                       t1, t2, drop_scale(t1), drop_scale(t2), aptai_seed_salt(stream));
     APTAI_CHECK_LAUNCH("head_act_bwd_kernel");
     return APTAI_OK;
 }
@@ -659,7 +659,7 @@ extern "C" int aptai_dropout_bf16(const void* x, void* y, int64_t n, float p, ui
     APTAI_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "aptai_dropout_bf16: buffers must be 16-byte aligned");
     const uint32_t t = drop_thr16(p);
     APTAI_LAUNCH(dropout_kernel, dim3(grid_for(n / 8 + 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
-                       (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t, drop_scale(t), aptai_seed_salt());
+                       (long)n, (uint32_t)seed, (uint32_t)(seed >> 32), t, drop_scale(t), aptai_seed_salt(stream));
     APTAI_CHECK_LAUNCH("dropout_kernel");
     return APTAI_OK;
 }

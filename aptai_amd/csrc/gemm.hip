@@ -1152,7 +1152,7 @@ int launch_gemm192(GemmArgs g, int nbatch, int nsplit, hipStream_t stream) {
 }  // namespace
 
 // validates one descriptor and fills the kernel arguments (tiles for the 128-tile kernel; the others recompute them)
-static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& nsplit) {
+static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& nsplit, const void* stream) {
     APTAI_REQUIRE(d != nullptr, "aptai_gemm_bf16: null descriptor");
     APTAI_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "aptai_gemm_bf16: empty problem M=%ld N=%ld K=%ld", (long)d->M,
                   (long)d->N, (long)d->K);
@@ -1183,7 +1183,7 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     g.aux = (const bf16_t*)d->aux; g.ldaux = d->ldaux;
     g.flags = d->flags;
     g.seed0 = (uint32_t)d->seed; g.seed1 = (uint32_t)(d->seed >> 32);
-    g.salt = aptai_seed_salt();
+    g.salt = aptai_seed_salt(stream);
     g.thr16 = drop_thr16(d->dropout_p);
     g.dscale = drop_scale(g.thr16);
     if (g.thr16 == 0) g.flags &= ~APTAI_EPI_DROPOUT;
@@ -1228,7 +1228,7 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GemmArgs g;
     int nbatch = 1, nsplit = 1;
-    const int brc = build_args(d, g, nbatch, nsplit);
+    const int brc = build_args(d, g, nbatch, nsplit, stream_);
     if (brc != APTAI_OK) return brc;
     const bool f32 = d->out_f32 != 0;
     float* final_out = (float*)d->C;
@@ -1317,7 +1317,7 @@ extern "C" int aptai_gemm_bf16_grouped(const aptai_gemm_desc* descs, int n, void
     for (int i = 0; i < n; ++i) {
         const aptai_gemm_desc* d = descs + i;
         int nbatch = 1, nsplit = 1;
-        const int brc = build_args(d, ga.p[i], nbatch, nsplit);
+        const int brc = build_args(d, ga.p[i], nbatch, nsplit, stream_);
         if (brc != APTAI_OK) return brc;
         APTAI_REQUIRE(nbatch == 1 && nsplit == 1 && !d->accumulate, "aptai_gemm_bf16_grouped: problem %d: no batching, split-K or accumulate", i);
         APTAI_REQUIRE(d->a_kmajor == descs[0].a_kmajor && d->b_kmajor == descs[0].b_kmajor && (d->out_f32 != 0) == (descs[0].out_f32 != 0),

@@ -225,7 +225,7 @@ extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* m
     const uint32_t thr = drop_thr16(dropout_p);
     void* dxd = thr ? dx_drop : nullptr;
     if (dx_drop && !thr) APTAI_FAIL(APTAI_ERR_INVALID, "aptai_layernorm_bwd: dx_drop given with dropout_p == 0");
-#define LN_BWD_G(NCH, G) APTAI_LAUNCH((ln_bwd_kernel<NCH, G>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows, beta_if_gelu_after, aptai_seed_salt())
+#define LN_BWD_G(NCH, G) APTAI_LAUNCH((ln_bwd_kernel<NCH, G>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dres, (bf16_t*)dx, (bf16_t*)dxd, (uint32_t)seed, (uint32_t)(seed >> 32), thr, drop_scale(thr), (float*)workspace, (long)rows, beta_if_gelu_after, aptai_seed_salt(stream))
 #define LN_BWD(NCH) do { if (beta_if_gelu_after) LN_BWD_G(NCH, true); else LN_BWD_G(NCH, false); } while (0)
     switch (cols / 256) {
         case 1: LN_BWD(1); break;

@@ -29,12 +29,38 @@ extern "C" int aptai_device_check(char* name, int name_len) {
     return APTAI_OK;
 }
 
-// Optional per-step salt for every dropout mask: a device pointer to two uint32 words that the seeded kernels XOR into
-// their (seed0, seed1).  Lets a captured hipGraph draw fresh masks on every replay (the host rewrites the two words
-// before the replay) while forward and backward of one step still regenerate identical masks.
-static const uint32_t* g_seed_salt = nullptr;
-extern "C" int aptai_set_seed_salt(const void* device_ptr_2xu32) {
-    g_seed_salt = (const uint32_t*)device_ptr_2xu32;
+// Optional per-step salt for every dropout mask, bound to a STREAM: a device pointer to two uint32 words that the seeded
+// kernels launched on that stream XOR into their (seed0, seed1).  Lets a captured hipGraph draw fresh masks on every replay
+// (the host rewrites the two words before the replay) while forward and backward of one step still regenerate identical
+// masks.  The binding is looked up at launch (= capture) time and travels as a kernel argument, so two runners that capture
+// on two streams, or a runner next to eager launches on another stream, never see each other's salt.
+#include <mutex>
+namespace {
+constexpr int SALT_SLOTS = 64;
+struct SaltSlot { const void* stream; const uint32_t* ptr; bool used; };
+SaltSlot g_salts[SALT_SLOTS];
+std::mutex g_salt_mu;
+}  // namespace
+
+extern "C" int aptai_set_seed_salt(void* stream, const void* device_ptr_2xu32) {
+    std::lock_guard<std::mutex> lk(g_salt_mu);
+    int free_slot = -1;
+    for (int i = 0; i < SALT_SLOTS; ++i) {
+        if (g_salts[i].used && g_salts[i].stream == stream) {
+            if (device_ptr_2xu32) g_salts[i].ptr = (const uint32_t*)device_ptr_2xu32;
+            else g_salts[i].used = false;
+            return APTAI_OK;
+        }
+        if (!g_salts[i].used && free_slot < 0) free_slot = i;
+    }
+    if (!device_ptr_2xu32) return APTAI_OK;                    // clearing a stream that has no binding
+    if (free_slot < 0) APTAI_FAIL(APTAI_ERR_INVALID, "aptai_set_seed_salt: more than %d streams carry a salt", SALT_SLOTS);
+    g_salts[free_slot] = {stream, (const uint32_t*)device_ptr_2xu32, true};
     return APTAI_OK;
 }
-const uint32_t* aptai_seed_salt(void) { return g_seed_salt; }
+const uint32_t* aptai_seed_salt(const void* stream) {
+    std::lock_guard<std::mutex> lk(g_salt_mu);
+    for (int i = 0; i < SALT_SLOTS; ++i)
+        if (g_salts[i].used && g_salts[i].stream == stream) return g_salts[i].ptr;
+    return nullptr;
+}

@@ -11,19 +11,93 @@ Works unchanged on CPU tensors with the gloo backend (used by the world_size-2 t
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 
+# How one flat gradient bucket is averaged over the ranks (APTAI_DP_ALGO, or the `algo=` argument of the reducers):
+#   "allreduce" : one dist.all_reduce (RCCL picks ring / tree and its channel count)
+#   "rs_ag"     : dist.reduce_scatter_tensor + dist.all_gather_into_tensor on the same flat buffer: each rank
+#                 owns 1/W of the bucket, so the two halves can be pipelined bucket against bucket by RCCL
+#   "a2a"       : the DIRECT pattern written out - all_to_all_single hands chunk j of every rank to rank j over the pairwise xGMI
+#                 link (all 7 links of a GPU busy at once, each with 1/W of the bucket), fp32 sum of the W received chunks,
+#                 all_gather_into_tensor of the reduced shards
+# All three produce the same averaged bucket (tests/test_cpu_dp.py runs each at world_size 2 over gloo).
+DP_ALGOS = ("allreduce", "rs_ag", "a2a")
+
+
+def default_algo() -> str:
+    a = os.environ.get("APTAI_DP_ALGO", "allreduce")
+    if a not in DP_ALGOS:
+        raise ValueError(f"APTAI_DP_ALGO={a!r}: expected one of {DP_ALGOS}")
+    return a
+
+
+def _backend_has_avg(group) -> bool:
+    try:
+        return dist.get_backend(group) == "nccl"
+    except Exception:                   # noqa: BLE001
+        return False
+
+
+class _BucketWork:
+    """Handle of one in-flight bucket average; wait() leaves the AVERAGE in `flat[:n]` (on the side stream for device buffers)."""
+
+    def __init__(self, flat, n, world, group, algo):
+        self.flat, self.n, self.world, self.group, self.algo = flat, n, world, group, algo
+        self.scale = 1.0 / world
+        self.handles = []
+        self.stage = None
+
+    def start(self):
+        flat, W, g = self.flat, self.world, self.group
+        if self.algo == "allreduce":
+            if _backend_has_avg(g):
+                self.handles.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=g, async_op=True))
+                self.scale = None
+            else:
+                self.handles.append(dist.all_reduce(flat, group=g, async_op=True))
+        elif self.algo == "rs_ag":
+            shard = torch.empty(flat.numel() // W, device=flat.device, dtype=flat.dtype)
+            if _backend_has_avg(g):
+                dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.AVG, group=g)
+                self.scale = None
+            else:                       # gloo has no reduce_scatter: the rehearsal sums the whole bucket and keeps its shard
+                tmp = flat.clone()
+                dist.all_reduce(tmp, group=g)
+                r = dist.get_rank(g)
+                shard.copy_(tmp.view(W, -1)[r])
+            self.handles.append(dist.all_gather_into_tensor(flat, shard, group=g, async_op=True))
+            self.stage = shard
+        else:                           # "a2a"
+            recv = torch.empty_like(flat)
+            dist.all_to_all_single(recv, flat, group=g)
+            shard = recv.view(W, -1).float().sum(0).mul_(1.0 / W).to(flat.dtype)
+            self.scale = None
+            self.handles.append(dist.all_gather_into_tensor(flat, shard, group=g, async_op=True))
+            self.stage = (recv, shard)
+        return self
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+
+def _padded(n: int, world: int) -> int:
+    return (n + world - 1) // world * world
+
 
 class GradBucketReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 48.0,
-                 comm_dtype: Optional[torch.dtype] = None, process_group=None):
+                 comm_dtype: Optional[torch.dtype] = None, process_group=None, algo: Optional[str] = None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.comm_dtype = comm_dtype
+        self.algo = algo or default_algo()
         cap = int(bucket_mb * 1024 * 1024)
         self.buckets: List[List[torch.nn.Parameter]] = []
         cur, cur_bytes = [], 0
@@ -59,16 +133,21 @@ class GradBucketReducer:
     def _on_grad(self, p):
         bi = self._bucket_of[id(p)]
         self._pending[bi] -= 1
+        # protocol: ONE backward pass per finish().  A second backward before finish() (gradient accumulation) would find the
+        # bucket already in flight without its second contribution - refuse instead of reducing stale sums.
+        if self._pending[bi] < 0:
+            raise RuntimeError("GradBucketReducer: a parameter received a second gradient before finish(); call finish() "
+                               "after every backward (gradient accumulation across backwards is not supported)")
         if self._pending[bi] == 0:
             self._launch(bi)
 
     def _flat_for(self, bi):
         b = self.buckets[bi]
-        n = sum(p.numel() for p in b)
+        n = _padded(sum(p.numel() for p in b), self.world)
         dt = self.comm_dtype or b[0].dtype
         f = self._flat[bi]
         if f is None or f.numel() != n or f.device != b[0].device:
-            f = torch.empty(n, device=b[0].device, dtype=dt)
+            f = torch.zeros(n, device=b[0].device, dtype=dt)
             self._flat[bi] = f
         return f
 
@@ -79,18 +158,28 @@ class GradBucketReducer:
         for p in b:
             views.append(flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self._had_grad[bi] = [p.grad is not None for p in b]
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b]
+        had = [p.grad is not None for p in b]
+        self._had_grad[bi] = had
+        src = [p.grad for p, h in zip(b, had) if h]
+        dst = [v for v, h in zip(views, had) if h]
+        empty = [v for v, h in zip(views, had) if not h]
+
+        def fill_and_start():
+            # parameters without a gradient this step (LayerDrop) contribute zeros, written straight into their slots of the
+            # flat buffer ON the communication stream (no temporaries whose memory another stream could recycle)
+            if empty:
+                torch._foreach_zero_(empty)
+            if dst:
+                torch._foreach_copy_(dst, src)
+            self._handles[bi] = _BucketWork(flat, off, self.world, self.group, self.algo).start()
         if flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream()
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
-                torch._foreach_copy_(views, grads)
-                self._handles[bi] = dist.all_reduce(flat, group=self.group, async_op=True)
+                fill_and_start()
         else:
-            torch._foreach_copy_(views, grads)
-            self._handles[bi] = dist.all_reduce(flat, group=self.group, async_op=True)
+            fill_and_start()
         self._launched[bi] = True
 
     def finish(self):
@@ -101,12 +190,16 @@ class GradBucketReducer:
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:
                 self._launch(bi)
-        inv = 1.0 / self.world
         for bi, b in enumerate(self.buckets):
-            self._handles[bi].wait()
             flat = self._flat[bi]
+            work = self._handles[bi]
             if flat.is_cuda:
+                with torch.cuda.stream(self._stream):
+                    work.wait()
                 torch.cuda.current_stream().wait_stream(self._stream)
+            else:
+                work.wait()
+            inv = work.scale
             off = 0
             outs, srcs = [], []
             for p, had in zip(b, self._had_grad[bi]):
@@ -118,7 +211,8 @@ class GradBucketReducer:
                 off += p.numel()
             if outs:
                 torch._foreach_copy_(outs, srcs)
-                torch._foreach_mul_(outs, inv)
+                if inv is not None:
+                    torch._foreach_mul_(outs, inv)
         self.reset()
 
     def reduce_existing_grads(self):
@@ -143,10 +237,11 @@ class GradGroupReducer:
     communication buffer per key (bf16 by default: a 12-layer base model is 12 x 14 MB + front/heads), so a layer is one
     collective of a size xGMI moves in ~0.2 ms while the next layer's backward takes ~0.6 ms."""
 
-    def __init__(self, comm_dtype: Optional[torch.dtype] = torch.bfloat16, process_group=None):
+    def __init__(self, comm_dtype: Optional[torch.dtype] = torch.bfloat16, process_group=None, algo: Optional[str] = None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.comm_dtype = comm_dtype
+        self.algo = algo or default_algo()
         self._flat = {}
         self._pending = []
         self._stream = None
@@ -154,11 +249,11 @@ class GradGroupReducer:
     def launch(self, key, tensors: List[torch.Tensor]) -> None:
         if self.world == 1 or not tensors:
             return
-        n = sum(t.numel() for t in tensors)
+        n = _padded(sum(t.numel() for t in tensors), self.world)
         dt = self.comm_dtype or tensors[0].dtype
         flat = self._flat.get(key)
         if flat is None or flat.numel() != n or flat.device != tensors[0].device or flat.dtype != dt:
-            flat = torch.empty(n, device=tensors[0].device, dtype=dt)
+            flat = torch.zeros(n, device=tensors[0].device, dtype=dt)
             self._flat[key] = flat
         views, off = [], 0
         for t in tensors:
@@ -170,20 +265,23 @@ class GradGroupReducer:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
                 torch._foreach_copy_(views, tensors)
-                h = dist.all_reduce(flat, group=self.group, async_op=True)
+                h = _BucketWork(flat, off, self.world, self.group, self.algo).start()
         else:
             torch._foreach_copy_(views, tensors)
-            h = dist.all_reduce(flat, group=self.group, async_op=True)
+            h = _BucketWork(flat, off, self.world, self.group, self.algo).start()
         self._pending.append((h, views, tensors))
 
     def finish(self) -> None:
-        inv = 1.0 / self.world
         for h, views, tensors in self._pending:
-            h.wait()
             if views[0].is_cuda:
+                with torch.cuda.stream(self._stream):
+                    h.wait()
                 torch.cuda.current_stream().wait_stream(self._stream)
+            else:
+                h.wait()
             torch._foreach_copy_(tensors, views)
-            torch._foreach_mul_(tensors, inv)
+            if h.scale is not None:
+                torch._foreach_mul_(tensors, h.scale)
         self._pending = []
 
 
@@ -257,6 +355,9 @@ def shard_batch(batch: dict, rank: int, world: int) -> dict:
     out = {}
     for k, v in batch.items():
         n = v.shape[0]
+        if n % world:
+            raise ValueError(f"shard_batch: {k!r} holds {n} utterances, not a multiple of world_size {world} "
+                             f"(the remainder would be dropped silently)")
         per = n // world
         out[k] = v[rank * per:(rank + 1) * per]
     return out

@@ -12,7 +12,6 @@ Differences from the shipped reference, all forced by defects recorded in SURVEY
 from __future__ import annotations
 
 import os
-import pickle
 from types import SimpleNamespace
 
 import numpy as np
@@ -20,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .config import W2V2Config
+from .config import W2V2Config, load_model_cfg
 from .hostlogic import TV_NAMES
 from .modules import CrossAttention, ForwardSumLoss, LowPassFilterLayer, PositionalEncoding, RNN
 from .w2v2_pr import Wav2Vec2_PR
@@ -163,8 +162,8 @@ class Force_APTAI(nn.Module):
         # wav2vec2 phoneme recognizer (models/force_aptai.py:60-78): config pickle + state dict written by the PR training script
         self.pr_model_path = pr_model_path
         pr_ckpt_path = os.path.join(pr_model_path, 'best-model-ckpt')
-        with open(os.path.join(pr_ckpt_path, 'model_cfg.pkl'), 'rb') as f:
-            self.w2v2_pr_cfg = pickle.load(f)          # a file the user's own PR training run wrote
+        # restricted unpickler: plain containers / values and configuration objects as attribute bags, nothing callable
+        self.w2v2_pr_cfg = load_model_cfg(os.path.join(pr_ckpt_path, 'model_cfg.pkl'))
         self.w2v2_pr = Wav2Vec2_PR(self.w2v2_pr_cfg['pretrain_cfg'], self.w2v2_pr_cfg['cache_dir'],
                                    self.w2v2_pr_cfg['huggingface_model_id'], vocab).to(self.device)
         self.w2v2_pr.load_state_dict(torch.load(os.path.join(pr_ckpt_path, 'pytorch_model.bin'),

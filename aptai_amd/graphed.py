@@ -35,6 +35,20 @@ from .wav2vec2 import _FinalLNImpl, _FrontImpl, _LayerImpl, _seed
 # and in the default "global" mode a call from ANY thread can invalidate the capture
 _CAPTURE_MODE = "thread_local"
 
+# stream handle -> the device tensor whose two words that stream's kernels XOR into their dropout seeds (kept alive here for
+# as long as the library holds the pointer)
+_SALTS: Dict[int, torch.Tensor] = {}
+
+
+def _bind_salt(stream_handle: int, salt: torch.Tensor) -> None:
+    _SALTS[stream_handle] = salt
+    _lib.call("aptai_set_seed_salt", stream_handle, salt.data_ptr())
+
+
+def _unbind_salt(stream_handle: int) -> None:
+    _lib.call("aptai_set_seed_salt", stream_handle, None)
+    _SALTS.pop(stream_handle, None)
+
 
 class GraphedAPTAIStep:
     def __init__(self, model: APTAI, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], reducer=None):
@@ -66,7 +80,10 @@ class GraphedAPTAIStep:
         self._salt_events = [None] * 4
         self._salt_turn = 0
         self._salt_gen = np.random.RandomState(0xC0FFEE + w.base_seed)
-        _lib.call("aptai_set_seed_salt", self.salt.data_ptr())
+        # the salt is bound to THIS runner's capture stream (include/aptai_hip.h: no process-global state); the module-level
+        # registry keeps the two words alive until the binding is cleared, whatever happens to the runner object
+        self._cap_stream = torch.cuda.Stream(device=dev)
+        _bind_salt(self._cap_stream.cuda_stream, self.salt)
         self.set_batch(batch)
         # one eager step first: allocates every persistent scratch buffer, loads the code objects and sets the kernel
         # attributes outside of stream capture
@@ -157,7 +174,7 @@ class GraphedAPTAIStep:
         w._cache_mode = "build"
         torch.cuda.synchronize()
         self.g_prep = mk()
-        with torch.cuda.graph(self.g_prep, pool=pool, capture_error_mode=_CAPTURE_MODE):
+        with torch.cuda.graph(self.g_prep, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
             w._conv_weights()
             if not getattr(self.opt, "publishes_copies", False):     # else the optimiser kernel refreshes the copies itself
                 w._refresh_layer_copies(force=True)
@@ -178,7 +195,7 @@ class GraphedAPTAIStep:
                         pc.parametrizations.weight.original0, pc.parametrizations.weight.original1, pc.bias,
                         w.encoder.layer_norm.weight, w.encoder.layer_norm.bias]
         self.g_front = mk()
-        with torch.cuda.graph(self.g_front, pool=pool, capture_error_mode=_CAPTURE_MODE):
+        with torch.cuda.graph(self.g_front, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
             if embed is not None and cfg.apply_spec_augment and cfg.mask_time_prob > 0:
                 ops.spec_augment_mask(self.lens_i32, g.B, g.T, cfg.mask_time_prob, cfg.mask_time_length, cfg.mask_time_min_masks,
                                       _seed(seed, 77), out=self.spec)        # fresh spans on every replay (salted seed)
@@ -193,7 +210,7 @@ class GraphedAPTAIStep:
             impl = _LayerImpl(cfg, g, self.lens_i32, wt, True, _seed(seed, 100 + i))
             params = [layer.layer_norm.weight, layer.layer_norm.bias, layer.final_layer_norm.weight, layer.final_layer_norm.bias] + lin
             gr = mk()
-            with torch.cuda.graph(gr, pool=pool, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(gr, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
                 (y,), s = impl.fwd(self.X[i], params, True)
             self.impl.append(impl); self.s_layer.append(s); self.g_fwd.append(gr); self.lparams.append(params)
             self.X.append(y)
@@ -208,7 +225,7 @@ class GraphedAPTAIStep:
             self.st_heads.norm_scalars = self.loss_norm.buffer(self.dev)
         self.fin = _FinalLNImpl(cfg, g) if cfg.do_stable_layer_norm else None
         self.g_tail = mk()
-        with torch.cuda.graph(self.g_tail, pool=pool, capture_error_mode=_CAPTURE_MODE):
+        with torch.cuda.graph(self.g_tail, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
             hl = self.X[L]
             if self.fin is not None:
                 (hl,), s_fin = self.fin.fwd(hl, [w.encoder.layer_norm.weight, w.encoder.layer_norm.bias], True)
@@ -230,7 +247,7 @@ class GraphedAPTAIStep:
         self.layer_grads = [None] * L
         for i in range(L - 1, -1, -1):
             gr = mk()
-            with torch.cuda.graph(gr, pool=pool, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(gr, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
                 dx, pg = self.impl[i].bwd(self.s_layer[i], (self.dX[i + 1],), True)
             self.g_bwd[i] = gr
             self.dX[i] = dx
@@ -238,7 +255,7 @@ class GraphedAPTAIStep:
 
         # -- front backward
         self.g_front_bwd = mk()
-        with torch.cuda.graph(self.g_front_bwd, pool=pool, capture_error_mode=_CAPTURE_MODE):
+        with torch.cuda.graph(self.g_front_bwd, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
             _, fg = self.front.bwd(self.s_front, (self.dX[0],), False)
         for p, gt in zip(self.fparams, fg):
             if p is not None and gt is not None:
@@ -309,7 +326,26 @@ class GraphedAPTAIStep:
         return out
 
     def close(self):
-        """Back to the eager loop: drop the per-step salt and the frozen weight cache."""
-        _lib.call("aptai_set_seed_salt", None)
-        self.w._cache_mode = None
-        self.w._cache.clear()
+        """Back to the eager loop: drop the salt binding of the capture stream and the frozen weight cache."""
+        if getattr(self, "_cap_stream", None) is not None:
+            _unbind_salt(self._cap_stream.cuda_stream)
+            self._cap_stream = None
+            self.w._cache_mode = None
+            self.w._cache.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        # a runner dropped without close() must not leave the library a pointer into a freed tensor; the model's weight
+        # cache is left alone here (a newer runner of the same model may own it by now)
+        try:
+            if getattr(self, "_cap_stream", None) is not None:
+                _unbind_salt(self._cap_stream.cuda_stream)
+                self._cap_stream = None
+        except Exception:               # noqa: BLE001 - interpreter shutdown
+            pass

@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py — utterances/sec of one APTAI train step (10 s @ 16 kHz) on 1..8 MI355X.
+"""bench.py — utterances/sec of one train step of APTAI's hot path (10 s @ 16 kHz clips) on 1..8 MI355X.
 
-Workload at N=1 (BASELINE.json configs[1]): models/aptai.py on a wav2vec2-base backbone with the 12-track
-regression head + 46-class frame phoneme head, batch 16 x 10 s, bf16 compute, conv feature encoder frozen
-(the reference default, models/aptai.py:24,39), dropout / LayerDrop / SpecAugment at the HF defaults.
-A "step" = zero_grad -> forward -> backward -> Adam step over one synthetic batch already resident in HBM.
-N>1: pure data parallel, 16 utterances per GPU (weak scaling), bucketed RCCL gradient all-reduce.
+Workloads (``--workload``; a "step" = zero_grad -> forward -> backward -> Adam step over one synthetic batch resident in HBM):
+  aptai (default, BASELINE.json configs[1]): models/aptai.py on wav2vec2-base, 12-track regression head + 46-class frame
+        phoneme head, 16 x 10 s per GPU, bf16, conv feature encoder frozen (models/aptai.py:24,39), regularisers at HF defaults.
+  force (configs[2]): models/force_aptai.py on wav2vec2-base + 40-phoneme CTC recogniser: frozen encoder in inference mode
+        (models/w2v2_pr.py:124-127), best-path decode, cross-attention aligner + forward-sum loss + BiLSTM regression; only
+        the heads train.
+  pr    (the fine-tuning loop behind configs[0], at 16 x 10 s): models/w2v2_pr.py, everything trainable incl. the conv stack,
+        CTC loss (train/train_phoneme_recognizer.py:384-486).
+N > 1: pure data parallel, one rank per GPU (weak scaling), gradient buckets averaged over RCCL.  ``python bench.py --gpus N``
+starts the N ranks itself (torch.distributed.run) when it was not already started by a launcher (WORLD_SIZE unset).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     — dominant kernel (bf16 MFMA GEMM, NT layout) timed live with HIP events on its launch stream
+  roofline     — dominant kernel family (bf16 MFMA GEMM, NT layout) timed live with HIP events on its launch stream
   cpu_baseline — the oracle (CPU restatement of the reference, oracle/) timed on this host's cores (N=1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -27,6 +34,7 @@ FWD_GF = {  # algorithmic GFLOP / utterance, forward (multiply-a
     ("base", 10.0): dict(conv=49.08, enc=99.05), ("large", 10.0): dict(conv=49.08, enc=334.76),
     ("base", 4.0): dict(conv=19.63, enc=37.30), ("large", 30.0): dict(conv=147.25, enc=1152.98),
 }
+PROFILE_TAG = "r02"
 
 
 def parse():
@@ -34,6 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="aptai", choices=["aptai", "force", "pr"])
     ap.add_argument("--model", default="base", choices=["base", "large"])
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 16 base / 8 large)")
     ap.add_argument("--seconds", type=float, default=10.0)
@@ -48,15 +57,56 @@ def parse():
     return ap.parse_args()
 
 
-def build_model(args, device):
-    from aptai_amd.aptai import APTAI
+# ------------------------------------------------------------------------------------------------- rank launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks_if_needed(args) -> None:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this file under torch.distributed.run and exit with
+    their status.  Runs BEFORE anything touches the GPU in this process (a process that initialised HIP must never be
+    replaced or forked into ranks); rank 0 of the children prints the JSON line on the inherited stdout."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world_env}")
+        return
+    if args.gpus <= 1:
+        return
+    backend = os.environ.get("APTAI_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        n_dev = torch.cuda.device_count()                    # counting devices does not initialise HIP on this image
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} GPU(s); refusing to measure fewer "
+                             f"ranks than asked (APTAI_BENCH_BACKEND=gloo rehearses the multi-rank path on one card)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    rc = subprocess.call(cmd, env=env)
+    raise SystemExit(rc)
+
+
+# ------------------------------------------------------------------------------------------------- models and batches
+def _cfg(args, vocab_size, **extra):
     from aptai_amd.config import W2V2Config
-    from aptai_amd.wav2vec2 import Wav2Vec2Model
-    kw = {}
+    kw = dict(extra)
     if args.no_regularisers:
-        kw = dict(hidden_dropout=0., activation_dropout=0., attention_dropout=0., feat_proj_dropout=0., final_dropout=0.,
+        kw.update(hidden_dropout=0., activation_dropout=0., attention_dropout=0., feat_proj_dropout=0., final_dropout=0.,
                   layerdrop=0., apply_spec_augment=False)
-    cfg = W2V2Config.base(vocab_size=46, **kw) if args.model == "base" else W2V2Config.large(vocab_size=46, **kw)
+    return W2V2Config.base(vocab_size=vocab_size, **kw) if args.model == "base" else W2V2Config.large(vocab_size=vocab_size, **kw)
+
+
+def build_aptai(args, device):
+    from aptai_amd.aptai import APTAI
+    from aptai_amd.wav2vec2 import Wav2Vec2Model
+    cfg = _cfg(args, 46)
     torch.manual_seed(0)                                   # identical random-init weights on every rank
     with tempfile.TemporaryDirectory() as tmp:
         Wav2Vec2Model(cfg).save_pretrained(tmp)
@@ -65,7 +115,47 @@ def build_model(args, device):
     return model.to(device), cfg
 
 
-def synth_batch(cfg, B, S, n_tv, rank, device):
+def _vocab40():
+    vocab = {"(blank)": 0, "(...)": 1}
+    vocab.update({f"p{i}": i for i in range(2, 40)})
+    return vocab
+
+
+def build_pr(args, device):
+    from aptai_amd.w2v2_pr import Wav2Vec2_PR
+    from aptai_amd.wav2vec2 import Wav2Vec2Model
+    cfg = _cfg(args, 40, ctc_loss_reduction="mean", ctc_zero_infinity=True)      # train/train_phoneme_recognizer.py:339-342
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        Wav2Vec2Model(cfg).save_pretrained(tmp)
+        model = Wav2Vec2_PR(cfg, None, tmp, _vocab40())
+    return model.to(device), cfg
+
+
+def build_force(args, device):
+    """Force_APTAI over a random-init Wav2Vec2_PR checkpoint written the way train_phoneme_recognizer.py writes it
+    (best-model-ckpt/{pytorch_model.bin, model_cfg.pkl}, models/force_aptai.py:60-75)."""
+    import pickle
+    from aptai_amd.force_aptai import Force_APTAI
+    from aptai_amd.w2v2_pr import Wav2Vec2_PR
+    from aptai_amd.wav2vec2 import Wav2Vec2Model
+    cfg = _cfg(args, 40, ctc_loss_reduction="mean", ctc_zero_infinity=True)
+    vocab = _vocab40()
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        mdir = os.path.join(tmp, "w2v2")
+        Wav2Vec2Model(cfg).save_pretrained(mdir)
+        pr = Wav2Vec2_PR(cfg, None, mdir, vocab)
+        ck = os.path.join(tmp, "pr", "best-model-ckpt")
+        os.makedirs(ck)
+        torch.save(pr.state_dict(), os.path.join(ck, "pytorch_model.bin"))
+        with open(os.path.join(ck, "model_cfg.pkl"), "wb") as f:
+            pickle.dump({"pretrain_cfg": cfg.to_dict(), "cache_dir": None, "huggingface_model_id": mdir}, f)
+        model = Force_APTAI(os.path.join(tmp, "pr"), device, vocab)
+    return model.to(device), cfg
+
+
+def synth_batch(cfg, B, S, n_tv, rank, device, n_phn=46):
     from aptai_amd import hostlogic
     g = torch.Generator().manual_seed(1234 + rank)
     lens = torch.full((B,), S, dtype=torch.long)
@@ -76,12 +166,56 @@ def synth_batch(cfg, B, S, n_tv, rank, device):
     fl = hostlogic.feat_extract_output_lengths(lens, cfg.conv_kernel, cfg.conv_stride)
     valid = torch.arange(T)[None, :] < fl[:, None]
     batch = {"audio_inputs": audio, "audio_lengths": lens,
-             "phn_frames_49hz": (torch.randint(1, 46, (B, T), generator=g) * valid).long()}
+             "phn_frames_49hz": (torch.randint(1, n_phn, (B, T), generator=g) * valid).long()}
     names = list(hostlogic.TV_NAMES) + [f"XTV{i}" for i in range(max(0, n_tv - 9))]
     for n in names[:n_tv]:
         tv = torch.randn(B, T, generator=g, dtype=torch.float64)
         batch[n] = torch.where(valid, tv, torch.full_like(tv, -100.0))
     return {k: v.to(device) for k, v in batch.items()}
+
+
+def synth_ctc_labels(B, vocab, rank, device, lo=20, hi=55):
+    """CTC label rows: lengths uniform in [20, 55] (< 60, models/force_aptai.py:111), ids in [1, V-1], -100 padding."""
+    g = torch.Generator().manual_seed(4321 + rank)
+    lens = torch.randint(lo, hi + 1, (B,), generator=g)
+    lab = torch.full((B, int(lens.max())), -100, dtype=torch.int32)
+    for b in range(B):
+        lab[b, :lens[b]] = torch.randint(1, vocab, (int(lens[b]),), generator=g, dtype=torch.int32)
+    return lab.to(device)
+
+
+def calibrate_blank_bias(model, batch, lo=20, hi=55):
+    """A trained recogniser emits blank on most frames; random-init weights emit ~T distinct labels per clip, more than the
+    aligner's 60 phoneme slots (models/force_aptai.py:30,111).  Raise the blank logit's bias until every utterance of the
+    synthetic batch decodes to a list of lo..hi phonemes (the length range of SURVEY.md 8d's CTC labels).  Setup only."""
+    import numpy as np
+    pr = model.w2v2_pr
+    with torch.no_grad():
+        _, logits = pr._logits_eval(batch["audio_inputs"], batch["audio_lengths"][:, None])
+        lg = logits.float().cpu().numpy()
+    best_other = lg[..., 1:].max(-1)
+    margin = np.sort((best_other - lg[..., 0]).reshape(-1))             # blank wins a frame iff bias > margin
+    bias, got = None, None
+    for q in np.linspace(0.80, 0.995, 40):
+        b = float(margin[int(q * (len(margin) - 1))])
+        l2 = lg.copy()
+        l2[..., 0] += b
+        ids = l2.argmax(-1)
+        ns = []
+        for row in ids:
+            keep = np.ones(len(row), dtype=bool)
+            keep[1:] = row[1:] != row[:-1]
+            r = row[keep]
+            ns.append(int((r != 0).sum()))
+        if max(ns) <= hi and (bias is None or min(ns) >= lo):
+            bias, got = b, ns
+            if min(ns) >= lo:
+                break
+    if bias is None:
+        raise SystemExit("bench.py: could not calibrate the blank bias of the synthetic recogniser")
+    with torch.no_grad():
+        pr.pr_head.bias[0] += bias
+    return bias, got
 
 
 def host_cores() -> int:
@@ -97,43 +231,65 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
+# ------------------------------------------------------------------------------------------------- CPU baseline (oracle)
 def cpu_baseline(args, cfg_gpu):
-    """Oracle train step (fp32, CPU): fwd + bwd + Adam on B=2 x the bench clip length, regularisers at defaults."""
+    """Oracle train step of the SAME workload (fp32, CPU) on B=2 x the bench clip length, regularisers at defaults."""
     import copy
     from oracle import heads_ref, synth
     from aptai_amd import hostlogic
     cores = host_cores()
     torch.set_num_threads(cores)
-    print(f"[bench] cpu_baseline on {cores} host threads ...", file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline ({args.workload}) on {cores} host threads ...", file=sys.stderr, flush=True)
     cfg = copy.deepcopy(cfg_gpu)
-    shapes = synth.aptai_param_shapes(cfg, n_tv=9, n_phn=46)
-    sd = synth.make_state_dict(shapes, 0)
-    train = [v.requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and "feature_extractor" not in k]
-    opt = torch.optim.Adam(train, lr=1e-5)
     S = int(16000 * args.seconds)
-    batch = synth.synth_aptai_batch(cfg, 2, S, seed=1234)
-    tv = [batch[n] for n in hostlogic.TV_NAMES]
+    T = int(hostlogic.feat_extract_output_lengths(S, cfg.conv_kernel, cfg.conv_stride))
+    if args.workload == "aptai":
+        sd = synth.make_state_dict(synth.aptai_param_shapes(cfg, n_tv=9, n_phn=46), 0)
+        train = [v.requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and "feature_extractor" not in k]
+        batch = synth.synth_aptai_batch(cfg, 2, S, seed=1234)
+        tv = [batch[n] for n in hostlogic.TV_NAMES]
+    elif args.workload == "pr":
+        sd = synth.make_state_dict(synth.pr_param_shapes(cfg), 0)
+        train = [v.requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32]
+        batch = synth.synth_pr_batch(cfg, 2, S, seed=1234)
+    else:
+        sd = synth.make_state_dict(synth.force_aptai_param_shapes(cfg, 40), 0)
+        train = [v.requires_grad_(True) for k, v in sd.items()
+                 if v.dtype == torch.float32 and not k.startswith("w2v2_pr.") and k != "pe_phn.pe"]
+        batch = synth.synth_aptai_batch(cfg, 2, S, seed=1234, n_phn=40)
+        tv = [batch[n] for n in hostlogic.TV_NAMES]
+        g = torch.Generator().manual_seed(5)
+        lists = [torch.randint(2, 40, (int(torch.randint(20, 56, (1,), generator=g)),), generator=g).numpy() for _ in range(2)]
+    opt = torch.optim.Adam(train, lr=1e-5)
     times = []
     for it in range(1 + args.cpu_baseline_steps):
         t0 = time.perf_counter()
         opt.zero_grad()
         keep = [bool(torch.rand([]) >= cfg.layerdrop) for _ in range(cfg.num_hidden_layers)]
-        T = int(hostlogic.feat_extract_output_lengths(S, cfg.conv_kernel, cfg.conv_stride))
-        fl = hostlogic.feat_extract_output_lengths(batch["audio_lengths"], cfg.conv_kernel, cfg.conv_stride)
-        am = torch.arange(T)[None] < fl[:, None]
         mask = None
-        if cfg.apply_spec_augment and cfg.mask_time_prob > 0:
+        if args.workload != "force" and cfg.apply_spec_augment and cfg.mask_time_prob > 0:
+            lens = batch["audio_lengths"] if args.workload == "aptai" else batch["input_lengths"]
+            fl = hostlogic.feat_extract_output_lengths(lens, cfg.conv_kernel, cfg.conv_stride)
+            am = torch.arange(T)[None] < fl[:, None]
             mask = torch.from_numpy(hostlogic.compute_mask_indices((2, T), cfg.mask_time_prob, cfg.mask_time_length,
                                                                    attention_mask=am, min_masks=cfg.mask_time_min_masks))
-        out = heads_ref.aptai_forward(sd, cfg, batch["audio_inputs"], batch["audio_lengths"], batch["phn_frames_49hz"], tv,
-                                      training=True, mask_time_indices=mask, layer_keep=keep)
+        if args.workload == "aptai":
+            out = heads_ref.aptai_forward(sd, cfg, batch["audio_inputs"], batch["audio_lengths"], batch["phn_frames_49hz"], tv,
+                                          training=True, mask_time_indices=mask, layer_keep=keep)
+        elif args.workload == "pr":
+            out = heads_ref.pr_forward(sd, cfg, batch["input_values"], batch["input_lengths"], batch["phoneme_labels"],
+                                       training=True, mask_time_indices=mask, layer_keep=keep)
+        else:                       # encoder in inference mode (models/w2v2_pr.py:124-127), heads in training mode
+            out = heads_ref.force_aptai_forward(sd, cfg, batch["audio_inputs"], batch["audio_lengths"], tv, phn_pred_list=lists,
+                                                training=True)
         out["loss"].backward()
         opt.step()
         times.append(time.perf_counter() - t0)
         print(f"[bench] cpu_baseline step {it}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
     t = sum(times[1:]) / len(times[1:])
+    what = {"aptai": "APTAI", "pr": "Wav2Vec2_PR", "force": "Force_APTAI"}[args.workload]
     return {"value": round(2 / t, 4), "unit": "utterances/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle APTAI train step (fp32 torch CPU restatement), wav2vec2-{args.model}, B=2 x {args.seconds:g} s, "
+            "sample": f"oracle {what} train step (fp32 torch CPU restatement), wav2vec2-{args.model}, B=2 x {args.seconds:g} s, "
                       f"1 warm-up + {args.cpu_baseline_steps} timed steps, {t:.2f} s/step"}
 
 
@@ -143,7 +299,7 @@ def ema_rmse_check(model, cfg, args, device):
     against the synthetic targets, their difference, and the RMSE between the two predictions."""
     import numpy as np
     from oracle import heads_ref
-    from aptai_amd import hostlogic, metrics
+    from aptai_amd import metrics
     S = int(16000 * args.seconds)
     batch = synth_batch(cfg, 2, S, args.n_tv, 7, device)
     names = [k for k in batch if k not in ("audio_inputs", "audio_lengths", "phn_frames_49hz")]
@@ -167,16 +323,17 @@ def ema_rmse_check(model, cfg, args, device):
     return {"build": round(r_build, 6), "oracle": round(r_ref, 6), "abs_diff": float(f"{abs(r_build - r_ref):.3e}"),
             "rmse_between_predictions": float(f"{float(np.sqrt(np.mean((a - b) ** 2))):.3e}"),
             "sample": f"eval forward, B=2 x {args.seconds:g} s, {len(names)} tracks, {int(valid.sum())} valid frames, same weights; "
-                      "tvs_metric_rmse averaged over tracks (utility.py:393-418)"}
+                      "tvs_metric_rmse averaged over tracks (utility.py:393-418); with random weights and N(0,1) targets both RMSEs "
+                      "are ~1, so abs_diff is insensitive - rmse_between_predictions is the honest distance"}
 
 
+# ------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
+    launch_ranks_if_needed(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     # one rank per GPU; APTAI_BENCH_BACKEND=gloo rehearses the multi-rank plumbing on a box with fewer GPUs than ranks
     backend = os.environ.get("APTAI_BENCH_BACKEND", "nccl")
@@ -192,53 +349,88 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from aptai_amd import ops
-    from aptai_amd.dp import GradBucketReducer
+    from aptai_amd.dp import GlobalLossNorm, GradBucketReducer, default_algo
     B = args.batch or (16 if args.model == "base" else 8)
     S = int(16000 * args.seconds)
-    model, cfg = build_model(args, device)
-    model.wav2vec2.base_seed += rank
+    wl = args.workload
+    data_note = "synthetic N(0,1) 16 kHz waveforms, random-init weights"
+    if wl == "aptai":
+        model, cfg = build_aptai(args, device)
+        w2v2 = model.wav2vec2
+        batch = synth_batch(cfg, B, S, args.n_tv, rank, device)
+        call = lambda: model(0, **batch)
+    elif wl == "pr":
+        model, cfg = build_pr(args, device)
+        w2v2 = model.wav2vec2
+        sb = synth_batch(cfg, B, S, 9, rank, device, n_phn=40)
+        batch = {"input_values": sb["audio_inputs"], "input_lengths": sb["audio_lengths"],
+                 "phoneme_labels": synth_ctc_labels(B, 40, rank, device)}
+        call = lambda: model(**batch)
+    else:
+        model, cfg = build_force(args, device)
+        w2v2 = model.w2v2_pr.wav2vec2
+        batch = synth_batch(cfg, B, S, 9, rank, device, n_phn=40)
+        batch["phoneme_labels"] = synth_ctc_labels(B, 40, rank, device)
+        bias, counts = calibrate_blank_bias(model, batch)
+        data_note += (f"; blank bias of the random-init recogniser raised by {bias:.3f} so that the best-path decode inside the "
+                      f"step yields {min(counts)}..{max(counts)} phonemes per clip (a trained recogniser's regime)")
+        call = lambda: model(0, **batch)
+    w2v2.base_seed += rank
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     if args.torch_adam:
         opt = torch.optim.Adam(params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, fused=True)
     else:                                                    # same update rule as one multi-tensor HIP kernel (csrc/optim.hip)
         from aptai_amd.optim import Adam
-        opt = Adam(params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8).publish_to(model)
+        opt = Adam(params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8)
+        if wl != "force":                                    # force: the encoder is frozen, nothing to publish
+            opt = opt.publish_to(model)
     reducer = GradBucketReducer(params, bucket_mb=48.0, comm_dtype=torch.bfloat16) if world > 1 else None
-    if world > 1:                            # masked-mean losses over the GLOBAL batch: DP gradients == single-process gradients
-        from aptai_amd.dp import GlobalLossNorm
+    if world > 1 and wl != "pr":             # masked-mean losses over the GLOBAL batch: DP gradients == single-process gradients
         model.dp_loss_norm = GlobalLossNorm()
-    batch = synth_batch(cfg, B, S, args.n_tv, rank, device)
 
     runner = None
-    if not args.eager:
+    use_graph = (not args.eager) and wl == "aptai"
+    if use_graph:
         from aptai_amd.graphed import GraphedAPTAIStep
+        capture_error = None
         try:
             if reducer is not None:
                 reducer.remove()             # gradients are reduced explicitly after the captured backward
-            if os.environ.get("APTAI_BENCH_FAIL_CAPTURE"):      # rehearsal of the fallback below
+            if os.environ.get("APTAI_BENCH_FAIL_CAPTURE") in ("1", f"rank{rank}"):     # rehearsal of the fallback below
                 raise RuntimeError("APTAI_BENCH_FAIL_CAPTURE is set")
             runner = GraphedAPTAIStep(model, opt, batch, reducer=reducer)
-            step = runner.step
-            if args.host_batch:              # the collate_fn's view of the boundary: host tensors in, H2D inside the step
-                host = {k: v.cpu().pin_memory() for k, v in batch.items()}
-                step = lambda: runner.step(host)
         except Exception as e:               # noqa: BLE001 - multi-rank only: same kernels through the eager loop, and say so
             if world == 1:
                 raise
-            print(f"[bench] rank {rank}: hipGraph capture failed ({e!r}); running the eager loop", file=sys.stderr, flush=True)
+            capture_error = e
             torch.cuda.synchronize()
-            runner = None
-            args.eager = True
-            from aptai_amd import _lib                   # what GraphedAPTAIStep.close() would have reset
-            _lib.call("aptai_set_seed_salt", None)
-            model.wav2vec2._cache_mode = None
-            model.wav2vec2._cache.clear()
-            reducer = GradBucketReducer(params, bucket_mb=48.0, comm_dtype=torch.bfloat16)
-    if args.eager:
+        if world > 1:
+            # the ranks must take the SAME path: the graph runner reduces per layer group, the eager loop per 48 MB bucket -
+            # different collective sequences on different ranks would hang or corrupt the gradients
+            ok = torch.tensor([0 if capture_error is not None else 1], device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if capture_error is not None:
+                    print(f"[bench] rank {rank}: hipGraph capture failed ({capture_error!r})", file=sys.stderr, flush=True)
+                if rank == 0:
+                    print("[bench] at least one rank could not capture: ALL ranks run the eager loop", file=sys.stderr, flush=True)
+                if runner is not None:
+                    runner.close()
+                runner = None
+                use_graph = False
+                w2v2._cache_mode = None
+                w2v2._cache.clear()
+                reducer = GradBucketReducer(params, bucket_mb=48.0, comm_dtype=torch.bfloat16)
+    if use_graph:
+        step = runner.step
+        if args.host_batch:                  # the collate_fn's view of the boundary: host tensors in, H2D inside the step
+            host = {k: v.cpu().pin_memory() for k, v in batch.items()}
+            step = lambda: runner.step(host)
+    else:
         def step():
             opt.zero_grad(set_to_none=True)
-            out = model(0, **batch)
+            out = call()
             out["loss"].backward()
             if reducer is not None:
                 reducer.finish()
@@ -262,7 +454,7 @@ def main():
     dt = time.perf_counter() - t0
     ops.set_gemm_probe(None)
     probe_note = "HIP events around every launch inside the timed region"
-    if not args.eager:
+    if use_graph:
         # kernels inside a hipGraph replay cannot be bracketed one by one: re-issue the SAME step eagerly right after the
         # timed region (same model, batch, shapes, regularisers) with the event probe on
         runner.close()
@@ -270,12 +462,12 @@ def main():
         ops.set_gemm_probe(probe)
         for _ in range(3):
             opt.zero_grad(set_to_none=True)
-            model(0, **batch)["loss"].backward()
+            call()["loss"].backward()
         torch.cuda.synchronize()
         ops.set_gemm_probe(None)
         probe_note = "HIP events around every launch of 3 eager re-runs of the same step right after the timed region"
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(out["loss"].detach())
@@ -283,44 +475,72 @@ def main():
         print(f"[bench] timed region: {dt / args.steps * 1e3:.2f} ms/step", file=sys.stderr, flush=True)
         ps = probe.summary()
         gemm_tflops = ps["flops"] / (ps["ms"] * 1e-3) / 1e12 if ps["ms"] > 0 else 0.0
-        traffic = None
-        try:                 # PMC traffic of the dominant kernel, collected offline (tools/pmc_summary.py), bytes per launch
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            nt = [v for k, v in pm.items() if "<false, false, false>" in k and "gemm" in k]      # the NT family the probe brackets
-            traffic = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_in_trace"] for v in nt) /
-                          max(sum(v["launches_in_trace"] for v in nt), 1))
-        except Exception:
-            pass
+        traffic, traffic_src = None, None
+        for tag in (PROFILE_TAG, "r01"):   # PMC traffic of the dominant kernel, collected offline (tools/pmc_summary.py)
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))["kernels"]
+                nt = [v for k, v in pm.items() if "<false, false, false>" in k and "gemm" in k]      # the NT family the probe brackets
+                traffic = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_in_trace"] for v in nt) /
+                              max(sum(v["launches_in_trace"] for v in nt), 1))
+                traffic_src = f"profiles/{tag}_pmc_traffic.json"
+                break
+            except Exception:
+                continue
+        if wl != "aptai":
+            traffic, traffic_src = None, None            # the PMC passes were collected on the aptai workload
         gf = FWD_GF.get((args.model, args.seconds))
-        step_tf = None
+        step_tf = step_tf_exec = None
         if gf:
-            step_tf = (gf["conv"] + 3 * gf["enc"]) * B / 1e3          # conv stack frozen: fwd only; encoder fwd+bwd
+            if wl == "aptai":          # conv stack frozen: fwd only; encoder fwd+bwd
+                step_tf = (gf["conv"] + 3 * gf["enc"]) * B / 1e3
+                # LayerDrop skips a layer's forward AND backward with probability p: the executed encoder work is (1 - p) of
+                # the layer share; `step_algorithmic_tflop` counts every layer (the reference's nominal work per step)
+                keep = 1.0 - (0.0 if args.no_regularisers else cfg.layerdrop)
+                step_tf_exec = (gf["conv"] + 3 * gf["enc"] * keep) * B / 1e3
+            elif wl == "pr":           # everything trainable: 3 x forward
+                step_tf = 3 * (gf["conv"] + gf["enc"]) * B / 1e3
+                keep = 1.0 - (0.0 if args.no_regularisers else cfg.layerdrop)
+                step_tf_exec = 3 * (gf["conv"] + gf["enc"] * keep) * B / 1e3
+            else:                      # encoder forward only (inference); heads < 0.1 %
+                step_tf = step_tf_exec = (gf["conv"] + gf["enc"]) * B / 1e3
+        what = {"aptai": f"APTAI train step (models/aptai.py): wav2vec2-{args.model} + {args.n_tv}-dim EMA regression head + "
+                         f"46-class frame phoneme head, conv feature encoder frozen",
+                "pr": f"Wav2Vec2_PR train step (models/w2v2_pr.py): wav2vec2-{args.model} + CTC head (40 phonemes), everything "
+                      f"trainable incl. the conv feature encoder",
+                "force": f"Force_APTAI train step (models/force_aptai.py): frozen wav2vec2-{args.model} CTC recogniser in inference "
+                         f"mode + best-path decode + cross-attention forced aligner (forward-sum loss) + BiLSTM 9-track "
+                         f"regression; only the heads train"}[wl]
         res = {
             "metric": "utterances/sec (10 s @ 16 kHz) train-step", "value": round(world * B * args.steps / dt, 3),
             "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic N(0,1) 16 kHz waveforms, random-init weights",
-            "config": {"workload": f"APTAI train step (models/aptai.py): wav2vec2-{args.model} + {args.n_tv}-dim EMA regression "
-                                   f"head + 46-class frame phoneme head, conv feature encoder frozen",
+            "vs_baseline": None, "dtype": "bf16", "data": data_note,
+            "config": {"workload": what,
                        "per_gpu_batch": B, "global_batch": world * B, "clip_seconds": args.seconds,
-                       "frames_per_clip": int(S // 320 - (1 if S % 320 < 80 else 0)) if False else None,
-                       "parallelism": f"dp{world}", "regularisers": "off" if args.no_regularisers else "HF defaults",
-                       "optimizer": "Adam, fp32 state (torch fused)" if args.torch_adam else "Adam, fp32 state (aptai_adam_multi, refreshes the bf16 weight copies)",
-                       "execution": "eager autograd loop" if args.eager else "hipGraph segments (aptai_amd.graphed)",
+                       "parallelism": f"dp{world}", "ranks": world,
+                       "collective": (f"{backend} ({'RCCL over xGMI' if backend == 'nccl' else 'rehearsal on CPU tensors'}), "
+                                      f"bucket average = {default_algo()}") if world > 1 else None,
+                       "regularisers": "off" if args.no_regularisers else "HF defaults",
+                       "optimizer": "Adam, fp32 state (torch fused)" if args.torch_adam else "Adam, fp32 state (aptai_adam_multi)",
+                       "execution": "hipGraph segments (aptai_amd.graphed)" if use_graph else "eager autograd loop",
                        "inputs": "pinned host batch copied in every step (PCIe-inclusive)" if args.host_batch else "resident in HBM"},
             "loss": round(loss, 5),
             "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM, NT layout (gemm_kernel / gemm192_kernel / gemm256_kernel <false,false,false>): every launch of the step",
                          "achieved": round(gemm_tflops, 2), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / 2500.0, 4), "traffic": traffic,
-                         "traffic_note": "HBM-side bytes per launch, launch-weighted over the same NT kernels, rocprofv3 PMC (2 x FETCH_SIZE + "
-                                         "WRITE_SIZE, separate passes), profiles/r01_pmc_traffic.json",
+                         "traffic_note": (f"HBM-side bytes per launch, launch-weighted over the same NT kernels, rocprofv3 PMC (2 x FETCH_SIZE + "
+                                          f"WRITE_SIZE, separate passes), {traffic_src}") if traffic else None,
                          "measured": probe_note, "launches": ps["launches"], "avg_launch_us": round(ps["ms"] * 1e3 / max(ps["launches"], 1), 2),
                          "step_algorithmic_tflop": step_tf,
-                         "whole_step_frac_of_peak": round(step_tf / (dt / args.steps) / 2500.0, 4) if step_tf else None},
+                         "step_executed_tflop": round(step_tf_exec, 4) if step_tf_exec else None,
+                         "whole_step_frac_of_peak": round(step_tf / (dt / args.steps) / 2500.0, 4) if step_tf else None,
+                         "whole_step_frac_of_peak_executed": round(step_tf_exec / (dt / args.steps) / 2500.0, 4) if step_tf_exec else None,
+                         "flop_note": "step_algorithmic_tflop counts every transformer layer (SURVEY.md 8d); LayerDrop (p = 0.1) skips "
+                                      "10 % of the layer work in expectation: *_executed prices the expected executed work"},
         }
-        res["config"].pop("frames_per_clip")
         if world == 1 and not args.no_cpu_baseline:
-            res["ema_rmse_vs_ref"] = ema_rmse_check(model, cfg, args, device)
+            if wl == "aptai":
+                res["ema_rmse_vs_ref"] = ema_rmse_check(model, cfg, args, device)
             res["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -24,9 +24,10 @@ def _model():
                                torch.nn.Linear(32, 4))
 
 
-def _worker(rank, world, port, comm_bf16, q):
+def _worker(rank, world, port, comm_bf16, q, algo="allreduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["APTAI_DP_ALGO"] = algo
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from aptai_amd.dp import GradBucketReducer, shard_batch
     model = _model()
@@ -52,13 +53,15 @@ def _worker(rank, world, port, comm_bf16, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("comm_bf16", [False, True])
-def test_dp_gradients_equal_single_process(comm_bf16):
+@pytest.mark.parametrize("comm_bf16,algo", [(False, "allreduce"), (True, "allreduce"), (False, "rs_ag"), (True, "a2a"), (False, "a2a")])
+def test_dp_gradients_equal_single_process(comm_bf16, algo):
+    """Every bucket-averaging pattern of aptai_amd.dp (all-reduce, reduce-scatter + all-gather, direct all-to-all) gives the
+    single-process gradient of the whole batch."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, comm_bf16, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, comm_bf16, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(world))
@@ -127,6 +130,21 @@ def test_shard_batch_is_contiguous():
     from aptai_amd.dp import shard_batch
     b = {"a": torch.arange(8), "b": torch.arange(16).view(8, 2)}
     assert shard_batch(b, 1, 4)["a"].tolist() == [2, 3] and shard_batch(b, 3, 4)["b"].tolist() == [[12, 13], [14, 15]]
+    with pytest.raises(ValueError):
+        shard_batch(b, 0, 3)                                # 8 utterances over 3 ranks: refuse, do not drop two
+
+
+def test_second_backward_before_finish_is_refused():
+    """GradBucketReducer's protocol is one backward per finish(): a second one must not silently reduce stale buckets."""
+    from aptai_amd.dp import GradBucketReducer
+    lin = torch.nn.Linear(4, 4)
+    red = GradBucketReducer(lin.parameters(), bucket_mb=1.0)
+    red.world = 2                                           # exercise the hook bookkeeping without a process group
+    red._launch = lambda bi: None
+    for p in red.params:
+        red._on_grad(p)
+    with pytest.raises(RuntimeError):
+        red._on_grad(red.params[0])
 
 
 def _norm_worker(rank, world, port, q):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import ROOT, load_golden
 from aptai_amd import hostlogic
 from aptai_amd.config import W2V2Config
 
@@ -153,3 +153,44 @@ def test_target_preparation_matches_reference_vectors(golden):
         got = hostlogic.match_phonemes_to_frames(z[f"match/{i}/bounds"].tolist(), z[f"match/{i}/labels"].tolist(), frame_duration=0.02)
         assert [-1 if v is None else int(v) for v in got] == z[f"match/{i}/out"].tolist()
 
+
+
+def test_model_cfg_pkl_loader_is_restricted(tmp_path):
+    """model_cfg.pkl (models/force_aptai.py:61-64) goes through a restricted unpickler: plain containers, torch.device and
+    configuration OBJECTS (rebuilt as attribute bags) load; any other global is refused before it can run."""
+    import pickle
+    from aptai_amd.config import W2V2Config, load_model_cfg
+    cfg = W2V2Config.base(vocab_size=40)
+    p = tmp_path / "a.pkl"
+    pickle.dump({"pretrain_cfg": cfg.to_dict(), "cache_dir": None, "huggingface_model_id": "/x", "device": torch.device("cpu")},
+                open(p, "wb"))
+    back = load_model_cfg(str(p))
+    assert W2V2Config.from_any(back["pretrain_cfg"]) == cfg and back["device"] == torch.device("cpu")
+    pickle.dump({"pretrain_cfg": cfg}, open(p, "wb"))                     # the build's own config object
+    assert W2V2Config.from_any(load_model_cfg(str(p))["pretrain_cfg"]) == cfg
+    try:                                                                   # what the reference pickles: an HF config object
+        from transformers import Wav2Vec2Config
+        hf = Wav2Vec2Config(vocab_size=40, hidden_size=768)
+        pickle.dump({"pretrain_cfg": hf, "cache_dir": None, "huggingface_model_id": "/x"}, open(p, "wb"))
+        got = W2V2Config.from_any(load_model_cfg(str(p))["pretrain_cfg"])
+        assert got.vocab_size == 40 and got.conv_kernel == tuple(hf.conv_kernel) and got.layerdrop == hf.layerdrop
+    except ImportError:
+        pass
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > /dev/null",))
+    pickle.dump({"pretrain_cfg": Evil()}, open(p, "wb"))
+    with pytest.raises(pickle.UnpicklingError):
+        load_model_cfg(str(p))
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """bench.py --gpus N under a launcher that started a different number of ranks must fail, not measure the wrong job."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
