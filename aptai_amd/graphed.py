@@ -158,6 +158,11 @@ class GraphedAPTAIStep:
 
     # ------------------------------------------------------------------ capture
     def _capture(self):
+        # fault injection for the multi-rank fallback rehearsal (bench.py, tests/test_gpu_bench.py): "1" = every rank,
+        # "rank<k>" = that rank only.  Placed here, after the constructor's eager step, where a real capture failure would occur.
+        inject = os.environ.get("APTAI_GRAPH_FAIL_CAPTURE")
+        if inject and inject in ("1", f"rank{os.environ.get('RANK', '0')}"):
+            raise RuntimeError("APTAI_GRAPH_FAIL_CAPTURE is set")
         model, w, cfg, g = self.model, self.w, self.cfg, self.g
         L = cfg.num_hidden_layers
         pool = torch.cuda.graph_pool_handle()

@@ -148,6 +148,74 @@ def validate(model, device, vocab, epoch, exp_dir, test_spk, val_dl, log_step=10
     }
 
 
+def _eval_frames(gt_frames, pred_frames):
+    """Frame-level scores shared by validate()/test() of both TV models (train/train_aptai.py:583-607, 717-749): number of
+    frames, number correct, overlap, boundary precision / recall / F1 / R-value as the reference calls `get_stats`."""
+    gt_f, p_f = gt_frames.cpu().numpy(), pred_frames.cpu().numpy()
+    y, yhat = gt_f.squeeze(), p_f.squeeze()
+    return (gt_frames.size(1), int(torch.sum(torch.eq(gt_frames, pred_frames.to(gt_frames.device))).item()),
+            metrics.evaluate_overlap(gt_f, p_f), metrics.get_stats(y, yhat, tolerance=0.02), y, yhat)
+
+
+def _stack_gt(batch_x):
+    """Ground-truth stack of validate()/test() AS WRITTEN in the reference: TTCD sits in the TMCD slot (:557-560, :702-705)."""
+    return torch.stack([batch_x["LA"], batch_x["LP"], batch_x["JA"], batch_x["TTCL"], batch_x["TTCD"], batch_x["TMCL"],
+                        batch_x["TTCD"], batch_x["TBCL"], batch_x["TBCD"]], dim=-1).float()
+
+
+def _tv_test_summary(rate, rmse_tvs, pcc_tvs, with_std=False):
+    names = hostlogic.TV_NAMES
+    m_rmse = {n: float(np.mean(rmse_tvs[n])) for n in names}
+    m_pcc = {n: float(np.mean(pcc_tvs[n])) for n in names}
+    out = {f"test_{rate}_mean_rmse": float(np.mean(list(m_rmse.values()))), f"test_{rate}_mean_pcc": float(np.mean(list(m_pcc.values())))}
+    if with_std:
+        out[f"test_{rate}_std_rmse"] = float(np.std(list(m_rmse.values())))
+        out[f"test_{rate}_std_pcc"] = float(np.std(list(m_pcc.values())))
+    for n in names:
+        out[f"test_{rate}_mean_{n}_pcc"] = m_pcc[n]
+    for n in names:
+        out[f"test_{rate}_mean_{n}_rmse"] = m_rmse[n]
+    return out
+
+
+def test(model, device, vocab, exp_dir, test_spk, test_dl, rate, log_step=100, num_epochs=0) -> Dict[str, float]:
+    """train/train_aptai.py:655-850, batch size 1: per-track RMSE / PCC means, FER, frame-grouped PER, overlap, boundary scores,
+    keyed `test_{rate}_...` with rate in {'F', 'N'} (fast / normal speaking rate splits of the corpus).  `num_epochs` stands for
+    the module-global `cfg.num_epochs` the reference passes as the epoch argument (:709)."""
+    assert rate in ["F", "N"]
+    names = hostlogic.TV_NAMES
+    rmse_tvs, pcc_tvs = {n: [] for n in names}, {n: [] for n in names}
+    overlaps, ps, rs, f1s, rvals, edit_d, n_phn = [], [], [], [], [], [], []
+    total_frames = corr_frames = 0
+    model.eval()
+    for batch_x in test_dl:
+        with torch.no_grad():
+            tvs_gt = _stack_gt(batch_x)
+            batch_x = {k: v.to(device) for k, v in batch_x.items()}
+            outputs = model(num_epochs, **batch_x)
+        tvs_gt = torch.squeeze(tvs_gt, dim=0).cpu().numpy()
+        tvs_pred = torch.squeeze(outputs["tvs_pred"], dim=0).float().cpu().numpy()
+        frames, corr, overlap, (p, r, f1, rval), y, yhat = _eval_frames(batch_x["phn_frames_49hz"], outputs["phn_fc_pred"])
+        total_frames += frames
+        corr_frames += corr
+        overlaps.append(overlap)
+        ps.append(p); rs.append(r); f1s.append(f1); rvals.append(rval)
+        y_grp, yhat_grp = metrics.phn_frame_id2phn(y.tolist()), metrics.phn_frame_id2phn(yhat.tolist())
+        edit_d.append(metrics.edit_distance(y_grp, yhat_grp))
+        n_phn.append(len(y_grp))
+        rm, pc = metrics.tvs_metric_rmse(tvs_gt, tvs_pred), metrics.tvs_metric_ppc(tvs_gt, tvs_pred)
+        for n in names:
+            rmse_tvs[n].append(rm[n])
+            pcc_tvs[n].append(pc[n][0])
+    out = _tv_test_summary(rate, rmse_tvs, pcc_tvs)
+    out.update({f"test_{rate}_mean_FER": 1 - (corr_frames / total_frames),
+                f"test_{rate}_mean_PER": float(np.sum(edit_d) / np.sum(n_phn)),
+                f"test_{rate}_mean_overlap": float(np.mean(overlaps)), f"test_{rate}_mean_F1": float(np.mean(f1s)),
+                f"test_{rate}_mean_p": float(np.mean(ps)), f"test_{rate}_mean_r": float(np.mean(rs)),
+                f"test_{rate}_mean_Rval": float(np.mean(rvals))})
+    return out
+
+
 def default_cfg(**kw):
     """Hyper-parameters at the reference's argparse defaults (train/train_aptai.py:45-140)."""
     cfg = SimpleNamespace(device="cuda", num_epochs=2, batch_size=16, learning_rate=1e-5, adam_beta1=0.9, adam_beta2=0.999,

@@ -397,8 +397,6 @@ def main():
         try:
             if reducer is not None:
                 reducer.remove()             # gradients are reduced explicitly after the captured backward
-            if os.environ.get("APTAI_BENCH_FAIL_CAPTURE") in ("1", f"rank{rank}"):     # rehearsal of the fallback below
-                raise RuntimeError("APTAI_BENCH_FAIL_CAPTURE is set")
             runner = GraphedAPTAIStep(model, opt, batch, reducer=reducer)
         except Exception as e:               # noqa: BLE001 - multi-rank only: same kernels through the eager loop, and say so
             if world == 1:

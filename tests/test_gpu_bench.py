@@ -34,6 +34,6 @@ def test_bench_launches_its_own_ranks():
 
 
 def test_capture_failure_on_one_rank_moves_every_rank_to_eager():
-    res, err = _run({"APTAI_BENCH_FAIL_CAPTURE": "rank1"})
+    res, err = _run({"APTAI_GRAPH_FAIL_CAPTURE": "rank1"})
     assert res["n_gpus"] == 2 and res["config"]["execution"] == "eager autograd loop"
     assert "ALL ranks run the eager loop" in err

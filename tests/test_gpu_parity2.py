@@ -1,0 +1,336 @@
+"""GPU parity, round 2: the pieces VERDICT r01 found untested on the HIP path.
+
+ * SpecAugment: the reference-generated `pr_base_mini_2x1s: specaug/*` fixture through the GPU model (same numpy seed -> same
+   spans -> same logits and loss), and the `masked_spec_embed` gradient against the oracle;
+ * LowPassFilterLayer: the FIR kernel alone on `ops_small: lowpass/*`, including the T < 51 taps case;
+ * one test per inference helper (models/aptai.py:125-179, models/w2v2_pr.py:124-277, models/force_aptai.py:188-322) against
+   the oracle;
+ * integer outputs (frame argmax, alignment indices, decoded phoneme ids) are compared EXACTLY on every frame whose oracle
+   decision margin exceeds eps = 2 x (measured max deviation of the deciding scores): a frame can only flip if two scores move
+   toward each other by more than their gap, so an index bug cannot hide behind the bf16 encoder.  The fraction of frames under
+   eps is reported (printed) and bounded.
+"""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TV = ("LA", "LP", "JA", "TTCL", "TTCD", "TMCL", "TMCD", "TBCL", "TBCD")
+
+
+def margin_exact(name, got_idx, ref_idx, ref_scores, got_scores, max_under=0.08, max_dev=None):
+    """Exact equality of argmax indices wherever the oracle's top-2 margin exceeds eps = 2 * max|got_scores - ref_scores|.
+    Returns (eps, fraction of decisions under eps)."""
+    ref_scores, got_scores = np.asarray(ref_scores, np.float64), np.asarray(got_scores, np.float64)
+    dev = float(np.abs(got_scores - ref_scores).max())
+    if max_dev is not None:
+        assert dev <= max_dev, f"{name}: scores deviate by {dev:.4f} > {max_dev}"
+    eps = 2.0 * dev
+    top2 = np.sort(ref_scores, axis=-1)[..., -2:]
+    margin = top2[..., 1] - top2[..., 0]
+    clear = margin > eps
+    got_idx, ref_idx = np.asarray(got_idx), np.asarray(ref_idx)
+    bad = (got_idx != ref_idx) & clear
+    frac = 1.0 - float(clear.mean())
+    print(f"[margin] {name}: max score deviation {dev:.4f}, eps {eps:.4f}, {frac * 100:.2f} % of {clear.size} decisions under eps, "
+          f"{int((got_idx != ref_idx).sum())} differ in total")
+    assert not bad.any(), f"{name}: {int(bad.sum())} index mismatches on clear-margin decisions (eps {eps:.4f})"
+    assert frac <= max_under, f"{name}: {frac:.3f} of the decisions sit under eps {eps:.4f}"
+    return eps, frac
+
+
+# ------------------------------------------------------------------------------------------------ SpecAugment
+def _pr_model(cfg, sd):
+    from aptai_amd.w2v2_pr import Wav2Vec2_PR
+    from safetensors.torch import save_file
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, "config.json"), "w") as f:
+            json.dump(cfg.to_dict(), f)
+        save_file({k[len("wav2vec2."):]: v.contiguous() for k, v in sd.items() if k.startswith("wav2vec2.")},
+                  os.path.join(tmp, "model.safetensors"))
+        vocab = {"(blank)": 0}
+        vocab.update({f"p{i}": i for i in range(1, 40)})
+        model = Wav2Vec2_PR(cfg, None, tmp, vocab)
+    model.load_state_dict(sd)
+    return model.cuda()
+
+
+def test_specaugment_fixture_on_the_hip_path(monkeypatch):
+    """HF `_mask_hidden_states` (HF:1272-1316) through the GPU model: with the numpy sampler (HF's RNG order) and the fixture's
+    seed the spans equal the reference's, so logits and loss must match `specaug/*`; the gradient that flows into
+    `masked_spec_embed` (one row sum over the masked frames) is compared with the oracle's."""
+    from aptai_amd import hostlogic, wav2vec2 as W
+    from aptai_amd.config import W2V2Config
+    from oracle import heads_ref, synth, w2v2_ref
+    z, meta = load_golden("pr_base_mini_2x1s")
+    cfg = W2V2Config.from_any(dict(meta["cfg"], apply_spec_augment=True))
+    assert cfg.mask_time_prob == 0.05 and cfg.mask_time_length == 10 and cfg.mask_time_min_masks == 2
+    sd = synth.make_state_dict(synth.pr_param_shapes(cfg), meta["seed"])
+    batch = {k: torch.from_numpy(z["in/" + k]) for k in ("input_values", "input_lengths", "phoneme_labels")}
+    model = _pr_model(cfg, sd)
+    model.train()
+    monkeypatch.setattr(W, "_SPEC_ON_DEVICE", False)           # numpy sampler, global RNG, HF's call order
+    np.random.seed(int(z["specaug/np_seed"]))
+    out = model(**{k: v.cuda() for k, v in batch.items()})
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    got = out["phoneme_logits"].float().cpu().numpy()[:, ::3]
+    ref = z["specaug/phoneme_logits_sub"]
+    assert np.abs(got - ref).max() < 4e-2 * np.abs(ref).max()
+    assert np.linalg.norm(got - ref) < 1.5e-2 * np.linalg.norm(ref)
+    assert abs(out["loss"].item() - float(z["specaug/loss"])) < 1e-2 * abs(float(z["specaug/loss"]))
+    # the mask made a difference (the un-masked fixture is `train/*`)
+    assert np.abs(got - z["train/phoneme_logits"][:, ::3]).max() > 10 * np.abs(got - ref).max()
+    # ---- masked_spec_embed gradient vs the oracle with the same spans
+    T = z["train/phoneme_logits"].shape[1]
+    fl = w2v2_ref.feat_extract_output_lengths(batch["input_lengths"], cfg)
+    am = torch.arange(T)[None] < fl[:, None]
+    np.random.seed(int(z["specaug/np_seed"]))
+    m = hostlogic.compute_mask_indices((2, T), 0.05, 10, attention_mask=am, min_masks=2)
+    sdo = {k: v.clone() for k, v in sd.items()}
+    emb = sdo["wav2vec2.masked_spec_embed"].requires_grad_(True)
+    pw = sdo["wav2vec2.feature_projection.projection.weight"].requires_grad_(True)
+    ro = heads_ref.pr_forward(sdo, cfg, training=True, mask_time_indices=torch.from_numpy(m), **batch)
+    ro["loss"].backward()
+    g_gpu = model.wav2vec2.masked_spec_embed.grad.double().cpu()
+    rel = ((g_gpu - emb.grad.double()).norm() / emb.grad.double().norm()).item()
+    assert rel < 6e-2, rel
+    # masked frames carry no gradient into the projection: its weight gradient matches too
+    gp = model.wav2vec2.feature_projection.projection.weight.grad.double().cpu()
+    assert ((gp - pw.grad.double()).norm() / pw.grad.double().norm()).item() < 8e-2
+    # explicit mask_time_indices (the other entry of the same code path) gives the same hidden states as the seeded sampler
+    model.zero_grad(set_to_none=True)
+    w = model.wav2vec2
+    np.random.seed(int(z["specaug/np_seed"]))
+    h1 = w(batch["input_values"].cuda(), attention_mask=batch["input_lengths"].cuda()[:, None]).last_hidden_state
+    h2 = w(batch["input_values"].cuda(), attention_mask=batch["input_lengths"].cuda()[:, None],
+           mask_time_indices=torch.from_numpy(m)).last_hidden_state
+    assert torch.equal(h1, h2)
+
+
+# ------------------------------------------------------------------------------------------------ low-pass FIR kernel
+def test_lowpass_fir_kernel_on_reference_vectors():
+    """LowPassFilterLayer (models/modules.py:13-61) alone: fp64 FIR, 'same' padding, incl. an input SHORTER than the 51 taps."""
+    from aptai_amd.modules import LowPassFilterLayer
+    z, _ = load_golden("ops_small")
+    lp = LowPassFilterLayer("cuda", 10, 49, 9)
+    assert np.array_equal(lp.lowpass.weight.cpu().numpy(), z["lowpass/taps"])                  # f64 bit-exact taps
+    for sfx in ("", "_short"):
+        x = torch.from_numpy(z["lowpass/in" + sfx]).cuda().requires_grad_(True)
+        y = lp(x)
+        assert y.dtype == torch.float32 and y.shape == x.shape
+        assert np.abs(y.detach().cpu().numpy() - z["lowpass/out" + sfx]).max() <= 1e-6
+        # backward = the same symmetric filter applied to the gradient (self-adjoint): <y, g> == <x, filt(g)>
+        g = torch.randn_like(y)
+        y.backward(g)
+        lhs = (y.detach().double() * g.double()).sum().item()
+        rhs = (x.detach().double() * x.grad.double()).sum().item()
+        assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ APTAI helper
+def test_get_aptai_output_against_the_oracle():
+    """models/aptai.py:125-179 on one waveform: TV tracks, frame logits, probabilities and the int64 frame argmax."""
+    from aptai_amd.aptai import APTAI
+    from aptai_amd.config import W2V2Config
+    from oracle import heads_ref, synth
+    from safetensors.torch import save_file
+    cfg = W2V2Config.large(num_hidden_layers=3, vocab_size=46)
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), 3)
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, "config.json"), "w") as f:
+            json.dump(cfg.to_dict(), f)
+        save_file({k[len("wav2vec2."):]: v.contiguous() for k, v in sd.items() if k.startswith("wav2vec2.")},
+                  os.path.join(tmp, "model.safetensors"))
+        model = APTAI("cuda", {f"p{i}": i for i in range(46)}, tmp, cfg, None)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    wav = torch.randn(24000, generator=torch.Generator().manual_seed(11)).numpy()
+    got = model.get_aptai_output(wav)
+    assert not model.training
+    a = torch.from_numpy(wav)[None]
+    T = 74
+    with torch.no_grad():
+        ref = heads_ref.aptai_forward(sd, cfg, a, torch.tensor([24000]), torch.ones(1, T, dtype=torch.long),
+                                      [torch.zeros(1, T, dtype=torch.float64)] * 9, training=False)
+    rl = ref["phn_logits"][0].numpy()
+    assert got["phn_fc_logits"].shape == rl.shape == (T, 46)
+    assert np.abs(got["phn_fc_logits"] - rl).max() < 4e-2 * np.abs(rl).max()
+    assert got["phn_fc_pred"].dtype == np.int64
+    # random-init frame logits are O(1) over 46 classes, i.e. near-uniform: many top-2 gaps are of bf16-noise size by
+    # construction (17 % measured), so only the exactness on clear margins is a statement about the kernels here
+    margin_exact("get_aptai_output frame argmax", got["phn_fc_pred"], ref["phn_fc_pred"][0].numpy(), rl, got["phn_fc_logits"],
+                 max_under=0.4, max_dev=0.06)
+    tv_ref = ref["tvs_pred"][0].numpy()
+    tv_got = np.stack([np.asarray(got["tvs_pred"][n]) for n in TV], -1)
+    assert np.abs(tv_got - tv_ref).max() < 4e-2 * np.abs(tv_ref).max()
+    pr = torch.softmax(ref["phn_logits"], -1).numpy()
+    assert got["phn_fc_probs"].shape == pr.T.shape                       # `.T` of (1,T,V): the reference's (V,T,1) layout
+    assert np.abs(got["phn_fc_probs"] - pr.T).max() < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ Wav2Vec2_PR helpers
+def _pr_setup():
+    from aptai_amd.config import W2V2Config
+    from oracle import synth
+    z, meta = load_golden("pr_base_mini_2x1s")
+    cfg = W2V2Config.from_any(meta["cfg"])
+    sd = synth.make_state_dict(synth.pr_param_shapes(cfg), meta["seed"])
+    sd["pr_head.bias"][0] += 1.0                                  # some blank frames, so that the decode has runs to collapse
+    model = _pr_model(cfg, sd)
+    wav = torch.randn(16000, generator=torch.Generator().manual_seed(21)).numpy()
+    return model, cfg, sd, wav
+
+
+def test_pr_inference_helpers_against_the_oracle():
+    """get_ctc_logits / pred_phn_seq / predict_phonemes_durations / get_embeddings (models/w2v2_pr.py:124-277).  The beam decoder
+    is absent on both sides (parity unpinned): decoded ids are compared with the oracle's best path, exactly when
+    every frame's argmax margin clears eps."""
+    from oracle import heads_ref
+    model, cfg, sd, wav = _pr_setup()
+    a = torch.from_numpy(wav)[None]
+    e = heads_ref.pr_get_embeddings(sd, cfg, a, torch.tensor([16000]))
+    rl = e["phoneme_logits"][0].numpy()
+    T = rl.shape[0]
+    lg = model.get_ctc_logits(wav)
+    assert lg.shape == rl.shape and lg.dtype == np.float32
+    assert np.abs(lg - rl).max() < 4e-2 * np.abs(rl).max()
+    eps, frac = margin_exact("pr frame argmax", lg.argmax(-1), rl.argmax(-1), rl, lg, max_under=0.15)
+    ref_ids = heads_ref.ctc_best_path(rl)
+    top2 = np.sort(rl, -1)[:, -2:]
+    all_clear = bool(((top2[:, 1] - top2[:, 0]) > eps).all())
+    vocab = model.vocab
+    got = model.pred_phn_seq(wav, vocab)
+    inv = {v: k for k, v in vocab.items()}
+    assert got["phn_seq_ipa"] == [inv[int(i)] for i in got["phn_seq_idx"]]
+    dur = model.predict_phonemes_durations(wav, vocab)
+    assert list(dur["phn_seq_idx"]) == list(got["phn_seq_idx"])
+    # timesteps: first frame of every emitted label, in seconds at len(wav) / T / 16000 per frame (models/w2v2_pr.py:218-226)
+    ids_gpu = lg.argmax(-1)
+    keep = np.ones(T, dtype=bool)
+    keep[1:] = ids_gpu[1:] != ids_gpu[:-1]
+    ts = np.nonzero(keep & (ids_gpu != 0))[0]
+    assert np.allclose(dur["phn_seq_dur"], ts * (len(wav) / T / 16000))
+    assert len(dur["phn_seq_dur"]) == len(dur["phn_seq_idx"]) and all(np.diff(dur["phn_seq_dur"]) > 0)
+    if all_clear:
+        assert list(got["phn_seq_idx"]) == list(ref_ids)
+    else:                          # frames under eps may flip: the decoded lists agree up to those frames
+        n_under = int(((top2[:, 1] - top2[:, 0]) <= eps).sum())
+        assert abs(len(got["phn_seq_idx"]) - len(ref_ids)) <= 2 * n_under
+    emb = model.get_embeddings(a.cuda(), torch.tensor([16000]).cuda())
+    h_ref = e["last_transf_hidden"].numpy()
+    h_got = emb["last_transf_hidden"].float().cpu().numpy()
+    assert h_got.shape == h_ref.shape == (1, cfg.hidden_size, T)
+    assert np.linalg.norm(h_got - h_ref) < 1.5e-2 * np.linalg.norm(h_ref)
+    assert emb["phoneme_logits"].shape == (1, 40, T) and emb["frame_seq_lens"].tolist() == [T]
+    assert list(emb["phn_pred_seq_idx"][0]) == list(got["phn_seq_idx"])
+    assert emb["features_hidden"] is None                              # the reference's extra conv pass has no reader
+
+
+# ------------------------------------------------------------------------------------------------ Force_APTAI
+def _force_setup():
+    from test_gpu_force import _build
+    from aptai_amd.config import W2V2Config
+    from oracle import synth
+    z, meta = load_golden("force_aptai_1x2s")
+    pr_cfg = W2V2Config.from_any(meta["pr_cfg"])
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, meta["vocab_len"]), meta["seed"])
+    sd["w2v2_pr.pr_head.bias"][0] += meta["blank_bias"]
+    model, _ = _build(meta, sd)
+    return model, pr_cfg, sd, z, meta
+
+
+def _att_scores(att_log, frame_lens, phn_lens):
+    """(frames, 60) score rows of the valid frames with the padded phoneme slots pushed far down on both sides alike."""
+    rows = []
+    for b, (t, n) in enumerate(zip(frame_lens, phn_lens)):
+        r = np.array(att_log[b, :t], np.float64)
+        r[:, n:] = -1e4
+        rows.append(r)
+    return np.concatenate(rows, 0)
+
+
+def test_force_alignment_indices_exact_outside_the_measured_noise():
+    """Alignment read-out (models/force_aptai.py:148-161) of the PRODUCT path (bf16 encoder in front): on the reference fixture
+    (B = 1) and against the oracle at B = 2, every frame whose top-2 log-attention margin exceeds eps = 2 x the measured
+    deviation of the log-attention must pick the identical phoneme slot and phoneme id."""
+    from oracle import heads_ref, synth
+    model, pr_cfg, sd, z, meta = _force_setup()
+    model.eval()
+    # ---- B = 2 against the oracle
+    batch = synth.synth_aptai_batch(pr_cfg, 2, 24000, seed=5, n_phn=40)
+    with torch.no_grad():
+        ref = heads_ref.force_aptai_forward(sd, pr_cfg, batch["audio_inputs"], batch["audio_lengths"], [batch[n] for n in TV])
+        res, g, lists, frame_lens, phn_lens, ids = model._run(batch["audio_inputs"].cuda(), batch["audio_lengths"].cuda(),
+                                                              phn_pred_list=ref["pred_ctc_phn_seq"])
+    att_gpu = res[5].view(g.B, g.Tp, 60)[:, :g.T].float().cpu().numpy()
+    att_ref = ref["att"].numpy()
+    align_gpu = res[8].view(g.B, g.Tp)[:, :g.T].cpu().numpy()
+    sg, sr = _att_scores(att_gpu, frame_lens, phn_lens), _att_scores(att_ref, frame_lens, phn_lens)
+    ig = np.concatenate([align_gpu[b, :t] for b, t in enumerate(frame_lens)])
+    ir = np.concatenate([ref["align_idx"][b, :t].numpy() for b, t in enumerate(frame_lens)])
+    eps, frac = margin_exact("force alignment B=2 vs oracle", ig, ir, sr, sg, max_under=0.10)
+    # phoneme ids behind the slots (the gather kernel): same rule, expressed on the returned lists
+    fp = res[4].cpu().numpy()
+    top2 = np.sort(sr, -1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > eps
+    got_ids = np.concatenate([fp[b, :t] for b, t in enumerate(frame_lens)])
+    ref_ids = np.concatenate([np.asarray(ref["pred_frame_phns"][b]) for b in range(2)])
+    assert got_ids.dtype == np.int64 and (got_ids[clear] == ref_ids[clear]).all()
+    # ---- B = 1 on the reference's own output
+    b1 = {k[len("b1/in/"):]: torch.from_numpy(z[k]).cuda() for k in z.files if k.startswith("b1/in/")}
+    with torch.no_grad():
+        out = model(0, **b1, _phn_pred_list=[z["b1/pred_ctc_phn_seq"]])
+        ro = heads_ref.force_aptai_forward(sd, pr_cfg, b1["audio_inputs"].cpu(), b1["audio_lengths"].cpu(),
+                                           [b1[n].cpu() for n in TV], phn_pred_list=[z["b1/pred_ctc_phn_seq"]])
+    assert [int(v) for v in ro["pred_frame_phns"][0]] == [int(v) for v in z["b1/pred_frame_phns"]]      # oracle == reference
+    n = len(z["b1/pred_ctc_phn_seq"])
+    sr1 = _att_scores(ro["att"].numpy(), [len(z["b1/pred_frame_phns"])], [n])
+    t2 = np.sort(sr1, -1)[:, -2:]
+    clear1 = (t2[:, 1] - t2[:, 0]) > eps
+    got1 = np.asarray(out["pred_frame_phns"][0])
+    assert (got1[clear1] == z["b1/pred_frame_phns"][clear1]).all()
+    print(f"[margin] force alignment B=1 vs reference fixture: {100 * (1 - clear1.mean()):.2f} % of {clear1.size} frames under eps, "
+          f"{int((got1 != z['b1/pred_frame_phns']).sum())} differ in total")
+
+
+def test_force_inference_helpers_against_the_oracle():
+    """get_alignment (models/force_aptai.py:188-236: the (N x T) log-attention) and get_faptai_output (:238-322)."""
+    from oracle import heads_ref
+    model, pr_cfg, sd, z, meta = _force_setup()
+    wav = z["b1/in/audio_inputs"][0][:int(z["b1/in/audio_lengths"][0])]           # the utterance without its batch padding
+    a = torch.from_numpy(wav)[None]
+    T = len(z["b1/pred_frame_phns"])
+    with torch.no_grad():
+        e = heads_ref.pr_get_embeddings(sd, pr_cfg, a, torch.tensor([len(wav)]), prefix="w2v2_pr.")
+        lst = [heads_ref.ctc_best_path(e["phoneme_logits"][0].numpy())]
+        assert len(lst[0]) >= 2 and e["phoneme_logits"].shape[1] == T
+        dummy = [torch.full((1, T), -100.0, dtype=torch.float64)] * 9
+        ref = heads_ref.force_aptai_forward(sd, pr_cfg, a, torch.tensor([len(wav)]), dummy, phn_pred_list=lst)
+    al = model.get_alignment(wav)["alignment"]
+    assert not model.training
+    N = len(lst[0])
+    out = model.get_faptai_output(wav)
+    if list(out["pred_ctc_phn_seq"][0]) != list(lst[0]):
+        pytest.skip("the bf16 encoder flipped a near-tie frame of the (parity-unpinned) best-path decode: lists differ")
+    assert al.shape == (N, T)
+    ra = ref["att"][0, :T, :N].numpy().T
+    assert np.abs(al - ra).max() < 1.0                                         # log-attention of O(40) energies
+    tv_ref = ref["tvs_pred"][0].numpy()
+    tv_got = np.stack([np.asarray(out["tvs_pred"][n]) for n in TV], -1)
+    assert np.abs(tv_got - tv_ref).max() < 4e-2 * np.abs(tv_ref).max()
+    sg = np.array(al.T, np.float64)
+    sr = np.array(ra.T, np.float64)
+    eps, _ = margin_exact("get_faptai_output alignment", np.argmax(sg, -1), ref["align_idx"][0].numpy(), sr, sg, max_under=0.10)
+    t2 = np.sort(sr, -1)[:, -2:]
+    clear = (t2[:, 1] - t2[:, 0]) > eps
+    assert (np.asarray(out["pred_frame_phns"])[clear] == np.asarray(ref["pred_frame_phns"][0])[clear]).all()
+    assert out["hidden_alignment"].shape == (1, T, 256) and out["hidden_tvs"].shape == (1, T, 512)
+    ha = ref["att_out"].numpy()
+    assert np.linalg.norm(out["hidden_alignment"].cpu().numpy() - ha) < 5e-2 * np.linalg.norm(ha)
