@@ -58,22 +58,28 @@ ARGTYPES = {
     "aptai_posconv_wgrad": [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _P],
     "aptai_posconv_gemm": [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I, _P],
     "aptai_adam_multi": [_P, _P, _I64, _I64, _F, _F, _F, _F, _F, _P],
-    "aptai_sgemm_f32": [_P, _I, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _F, _I, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P],
+    "aptai_sgemm_f32": [_P, _I, _I64, _I64, _P, _I64, _I64, _P, _I64, _P, _F, _I, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P],
+    "aptai_sgemm_workspace_bytes": [_I64, _I64, _I64, _I64],
+    "aptai_colsum_f32_workspace_bytes": [_I64],
     "aptai_embed_pe_fwd": [_P, _P, _P, _P, _I64, _I64, _I64, _F, _U64, _P],
     "aptai_embed_bwd": [_P, _P, _P, _I64, _I64, _F, _U64, _P],
-    "aptai_xattn_softmax_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
-    "aptai_xattn_softmax_bwd": [_P, _P, _P, _P, _P, _I64, _I64, _P],
+    "aptai_xattn_softmax_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
+    "aptai_xattn_softmax_bwd": [_P, _P, _P, _P, _I64, _P, _I64, _I64, _P],
     "aptai_layernorm_f32_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P],
     "aptai_layernorm_f32_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P],
-    "aptai_lstm_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
-    "aptai_lstm_bwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "aptai_lstm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "aptai_lstm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "aptai_lstm_workspace_bytes": [_I64],
+    "aptai_lstm_fwd_serial": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "aptai_lstm_bwd_serial": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "aptai_gather_alignment": [_P, _P, _P, _P, _I64, _I64, _I64, _P],
     "aptai_tanh_dropout_f32": [_P, _P, _P, _P, _I64, _F, _U64, _P],
     "aptai_dropout_f32": [_P, _P, _I64, _F, _U64, _P],
-    "aptai_colsum_f32": [_P, _I64, _P, _I64, _I64, _P],
-    "aptai_ctc_fwd": [_P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _P, _P],
-    "aptai_ctc_bwd": [_P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _F, _P, _I64, _I, _P],
+    "aptai_colsum_f32": [_P, _I64, _P, _P, _I64, _I64, _P],
+    "aptai_ctc_fwd": [_P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    "aptai_ctc_bwd": [_P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _F, _P, _I64, _I, _I, _P],
     "aptai_ctc_workspace_bytes": [_I64, _I64, _I64],
+    "aptai_ctc_greedy_decode": [_P, _I64, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
     "aptai_device_check": [ctypes.c_char_p, _I],
     "aptai_set_seed_salt": [_P, _P],
 }

@@ -7,83 +7,149 @@
 
 namespace {
 
-// ------------------------------------------------------------------------------------------ generic fp32 GEMM
+// ------------------------------------------------------------------------------------------ generic fp32 GEMM on the matrix cores
 // C[m][n] (+)= alpha * sum_k A(m,k) * B(k,n) + bias[n];  A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn].
-// 64x64x16 tile, 256 threads, 4x4 outputs per thread.  A may be bf16 (the encoder's hidden states).
+// v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-for-bit a k-ordered fmaf chain (exact fp32, guide "FP32-input MFMA"), at
+// the fp32 vector peak but with ONE operand register per lane and no LDS traffic per FMA.  64 x 64 x 32 tile, 4 waves, each a
+// 32 x 32 sub-tile = 16 MFMAs per K-tile.  Operands go through LDS as [k][m] / [k][n] (pitch 65: conflict-free scatter from
+// either source orientation, conflict-free 32-lane row reads).  16-byte global loads whenever the contiguous axis allows it,
+// scalar guarded loads on ragged tiles.  A may be bf16 (the encoder's hidden states).  split_k > 1: K is cut into slabs whose
+// partial tiles go to a workspace and are summed in slab order by sgemm_reduce_kernel (deterministic).
+constexpr int SG_BK = 32, SG_P = 65;
+typedef __attribute__((ext_vector_type(4))) float sg_f4;
 struct SgemmArgs {
-    const void* A; const float* B; float* C; const float* bias;
+    const void* A; const float* B; float* C; const float* bias; float* ws;
     long sam, sak, sbk, sbn, ldc;
     long bsa, bsb, bsc;           // batch strides (elements)
-    int M, N, K, a_bf16, accumulate;
+    long kchunk;
+    int M, N, K, a_bf16, accumulate, split_k, vec_a, vec_b;
     float alpha;
 };
 
-__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
-    __shared__ float As[16][68];
-    __shared__ float Bs[16][68];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+__global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
+    __shared__ float As[SG_BK * SG_P];
+    __shared__ float Bs[SG_BK * SG_P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const long boff = blockIdx.z;
-    const float* Af = (const float*)g.A + boff * g.bsa;
-    const bf16_t* Ab = (const bf16_t*)g.A + boff * g.bsa;
-    const float* B = g.B + boff * g.bsb;
-    float* C = g.C + boff * g.bsc;
-    float acc[4][4];
+    const int bz = blockIdx.z / g.split_k, sz = blockIdx.z % g.split_k;
+    const long kbeg = (long)sz * g.kchunk;
+    const long kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    const float* Af = (const float*)g.A + (long)bz * g.bsa;
+    const bf16_t* Ab = (const bf16_t*)g.A + (long)bz * g.bsa;
+    const float* Bp = g.B + (long)bz * g.bsb;
+    f32x16 acc = (f32x16)(0.f);
+    const bool m_full = m0 + 64 <= g.M, n_full = n0 + 64 <= g.N;
+    for (long k0 = kbeg; k0 < kend; k0 += SG_BK) {
+        const bool k_full = k0 + SG_BK <= kend;
+        // ---- A tile: 64 (m) x 32 (k) -> As[k][m]
+        if (g.vec_a && m_full && k_full && g.sak == 1) {
+            if (g.a_bf16) {                                   // 8 bf16 per thread
+                const int row = tid >> 2, k8 = (tid & 3) * 8;
+                const u32x4 v = *(const u32x4*)(Ab + (long)(m0 + row) * g.sam + k0 + k8);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    As[(k8 + 2 * j) * SG_P + row] = lo_bf(v[j]);
+                    As[(k8 + 2 * j + 1) * SG_P + row] = hi_bf(v[j]);
+                }
+            } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
+                for (int e = 0; e < 2; ++e) {
+                    const int idx = e * 256 + tid, row = idx >> 3, k4 = (idx & 7) * 4;
+                    const sg_f4 v = *(const sg_f4*)(Af + (long)(m0 + row) * g.sam + k0 + k4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = e * 256 + tid;
-            {   // A tile: 64 (m) x 16 (k); consecutive threads walk the contiguous axis
+                    for (int j = 0; j < 4; ++j) As[(k4 + j) * SG_P + row] = v[j];
+                }
+            }
+        } else if (g.vec_a && m_full && k_full && g.sam == 1 && !g.a_bf16) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = e * 256 + tid, kk = idx >> 4, m4 = (idx & 15) * 4;
+                const sg_f4 v = *(const sg_f4*)(Af + (k0 + kk) * g.sak + m0 + m4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[kk * SG_P + m4 + j] = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = e * 256 + tid;
                 int mm, kk;
-                if (g.sak == 1) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
-                const int m = m0 + mm, k = k0 + kk;
+                if (g.sak == 1) { kk = idx & 31; mm = idx >> 5; } else { mm = idx & 63; kk = idx >> 6; }
+                const int m = m0 + mm;
+                const long k = k0 + kk;
                 float v = 0.f;
-                if (m < g.M && k < g.K) {
-                    const long off = (long)m * g.sam + (long)k * g.sak;
+                if (m < g.M && k < kend) {
+                    const long off = (long)m * g.sam + k * g.sak;
                     v = g.a_bf16 ? bf2f(Ab[off]) : Af[off];
                 }
-                As[kk][mm] = v;
+                As[kk * SG_P + mm] = v;
             }
-            {   // B tile: 16 (k) x 64 (n)
+        }
+        // ---- B tile: 32 (k) x 64 (n) -> Bs[k][n]
+        if (g.vec_b && n_full && k_full && g.sbn == 1) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = e * 256 + tid, kk = idx >> 4, n4 = (idx & 15) * 4;
+                const sg_f4 v = *(const sg_f4*)(Bp + (k0 + kk) * g.sbk + n0 + n4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[kk * SG_P + n4 + j] = v[j];
+            }
+        } else if (g.vec_b && n_full && k_full && g.sbk == 1) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = e * 256 + tid, col = idx >> 3, k4 = (idx & 7) * 4;
+                const sg_f4 v = *(const sg_f4*)(Bp + (long)(n0 + col) * g.sbn + k0 + k4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(k4 + j) * SG_P + col] = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = e * 256 + tid;
                 int nn, kk;
-                if (g.sbn == 1) { nn = idx & 63; kk = idx >> 6; } else { kk = idx & 15; nn = idx >> 4; }
-                const int n = n0 + nn, k = k0 + kk;
+                if (g.sbn == 1) { nn = idx & 63; kk = idx >> 6; } else { kk = idx & 31; nn = idx >> 5; }
+                const int n = n0 + nn;
+                const long k = k0 + kk;
                 float v = 0.f;
-                if (n < g.N && k < g.K) v = B[(long)k * g.sbk + (long)n * g.sbn];
-                Bs[kk][nn] = v;
+                if (n < g.N && k < kend) v = Bp[k * g.sbk + (long)n * g.sbn];
+                Bs[kk * SG_P + nn] = v;
             }
         }
         __syncthreads();
+        const float* ap = As + (lane >> 5) * SG_P + wm * 32 + (lane & 31);
+        const float* bp = Bs + (lane >> 5) * SG_P + wn * 32 + (lane & 31);
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-        }
+        for (int kk = 0; kk < SG_BK / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * SG_P], bp[2 * kk * SG_P], acc, 0, 0, 0);
         __syncthreads();
     }
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n >= g.N) return;
+    const float bias = (g.bias && g.split_k == 1) ? g.bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= g.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (n >= g.N) continue;
-            float v = acc[i][j] * g.alpha + (g.bias ? g.bias[n] : 0.f);
-            float* c = C + (long)m * g.ldc + n;
+        if (g.split_k > 1) {
+            g.ws[((long)blockIdx.z * g.M + m) * g.N + n] = acc[r];
+        } else {
+            float* c = g.C + (long)bz * g.bsc + (long)m * g.ldc + n;
+            const float v = acc[r] * g.alpha + bias;
             *c = g.accumulate ? *c + v : v;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void sgemm_reduce_kernel(SgemmArgs g, int batch) {
+    const long total = (long)batch * g.M * g.N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % g.N);
+        const long mb = i / g.N;
+        const int m = (int)(mb % g.M), bz = (int)(mb / g.M);
+        float s = 0.f;
+        for (int z = 0; z < g.split_k; ++z) s += g.ws[(((long)bz * g.split_k + z) * g.M + m) * g.N + n];
+        float* c = g.C + (long)bz * g.bsc + (long)m * g.ldc + n;
+        const float v = s * g.alpha + (g.bias ? g.bias[n] : 0.f);
+        *c = g.accumulate ? *c + v : v;
     }
 }
 
@@ -117,8 +183,8 @@ __global__ void embed_bwd_kernel(const int* __restrict__ ids, const float* __res
 // att_log = log_softmax(energy + mask1) (the reference adds the -1000 mask twice); align = argmax(att_log) (first max)
 __global__ __launch_bounds__(256) void xattn_softmax_fwd_kernel(const float* __restrict__ raw, const int* __restrict__ ids,
                                                                 float* __restrict__ energy, float* __restrict__ att,
-                                                                float* __restrict__ att_log, int64_t* __restrict__ align, int B,
-                                                                int T, int N) {
+                                                                float* __restrict__ att_log, int64_t* __restrict__ align,
+                                                                float* __restrict__ fs_rows, int B, int T, int N) {
     const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (row >= (long)B * T) return;
@@ -136,6 +202,11 @@ __global__ __launch_bounds__(256) void xattn_softmax_fwd_kernel(const float* __r
     se = wave_sum(ex);
     const float al = e2 - (mx + logf(se));
     if (ok) att_log[row * N + lane] = al;
+    // forward-sum input row (models/modules.py:90-98): [blank log-prob -1 | att_log | zero padding] in a 64-float row
+    if (fs_rows) {
+        const float up = __shfl_up(al, 1, 64);
+        fs_rows[row * 64 + lane] = lane == 0 ? -1.f : (lane <= N ? up : 0.f);
+    }
     // argmax with first-index tie break
     float best = ok ? al : -INFINITY;
     int bi = lane;
@@ -150,13 +221,13 @@ __global__ __launch_bounds__(256) void xattn_softmax_fwd_kernel(const float* __r
 // d_raw = att*(d_att - sum(att*d_att)) + d_attlog - exp(att_log)*sum(d_attlog)
 __global__ __launch_bounds__(256) void xattn_softmax_bwd_kernel(const float* __restrict__ att, const float* __restrict__ att_log,
                                                                 const float* __restrict__ d_att, const float* __restrict__ d_attlog,
-                                                                float* __restrict__ d_raw, long rows, int N) {
+                                                                long ld_dattlog, float* __restrict__ d_raw, long rows, int N) {
     const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
     const bool ok = lane < N;
     const float a = ok ? att[row * N + lane] : 0.f, da = (ok && d_att) ? d_att[row * N + lane] : 0.f;
-    const float al = ok ? att_log[row * N + lane] : 0.f, dl = (ok && d_attlog) ? d_attlog[row * N + lane] : 0.f;
+    const float al = ok ? att_log[row * N + lane] : 0.f, dl = (ok && d_attlog) ? d_attlog[row * ld_dattlog + lane] : 0.f;
     const float s1 = wave_sum(a * da), s2 = wave_sum(dl);
     if (ok) d_raw[row * N + lane] = a * (da - s1) + dl - __expf(al) * s2;
 }
@@ -208,7 +279,9 @@ __global__ __launch_bounds__(256) void ln32_bwd_kernel(const float* __restrict__
     for (int j = 0; j < per; ++j) dx[row * cols + j * 64 + lane] = rs * (gd[j] - s1 - xh[j] * s2);
 }
 
-// ------------------------------------------------------------------------------------------ BiLSTM (hidden 256)
+// ------------------------------------------------------------------------------------------ BiLSTM (hidden 256), serial form
+// The first build's kernels: one block per (utterance, direction) that re-streams W_hh from L2 on every frame.  Kept as the
+// on-device cross-check of the cooperating-workgroup kernels in lstm.hip (tests/test_gpu_force.py); not on the hot path.
 // grid (B, 2 directions), 256 threads = hidden units.  xproj [B*Tp][2][4*HID] holds x W_ih^T + b_ih + b_hh;
 // whhT [2][HID][4*HID] (transposed: coalesced over the gate column).  Packed-sequence semantics: only t < len[b].
 constexpr int HID = 256;
@@ -330,11 +403,31 @@ __global__ void drop32_kernel(const float* __restrict__ x, float* __restrict__ y
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         y[i] = drop_keep((uint64_t)i, s0, s1, thr) ? x[i] * sc : 0.f;
 }
-__global__ void colsum32_kernel(const float* __restrict__ x, long ld, float* __restrict__ out, long rows, int N) {
+// column sums of an fp32 matrix in two deterministic stages: [chunks][N] partials (lane = column, the 4 waves of a block
+// interleave rows, coalesced 256-byte row segments), then one thread per column adds the chunks in order
+constexpr int CS_CHUNKS = 64;
+__global__ __launch_bounds__(256) void colsum32_part_kernel(const float* __restrict__ x, long ld, float* __restrict__ ws, long rows, int N,
+                                                            long rows_per_chunk) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const long r0 = (long)blockIdx.y * rows_per_chunk;
+    const long r1 = (r0 + rows_per_chunk < rows) ? r0 + rows_per_chunk : rows;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < N) {
+        long r = r0 + wave;
+        for (; r + 4 < r1; r += 8) { s0 += x[r * ld + c]; s1 += x[(r + 4) * ld + c]; }
+        for (; r < r1; r += 4) s0 += x[r * ld + c];
+    }
+    part[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && c < N) ws[(long)blockIdx.y * N + c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+__global__ void colsum32_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int chunks, int N) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N) return;
     float s = 0.f;
-    for (long r = 0; r < rows; ++r) s += x[r * ld + c];
+    for (int k = 0; k < chunks; ++k) s += ws[(long)k * N + c];
     out[c] = s;
 }
 
@@ -345,17 +438,38 @@ inline unsigned gridn(long n, int block = 256, int maxb = 2048) {
 
 }  // namespace
 
+extern "C" int64_t aptai_sgemm_workspace_bytes(int64_t M, int64_t N, int64_t batch, int64_t split_k) {
+    return split_k > 1 ? batch * split_k * M * N * 4 : 0;
+}
+
 extern "C" int aptai_sgemm_f32(const void* A, int a_bf16, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
                                float* C, int64_t ldc, const float* bias, float alpha, int accumulate, int64_t M, int64_t N,
-                               int64_t K, int64_t batch, int64_t bsa, int64_t bsb, int64_t bsc, void* stream) {
+                               int64_t K, int64_t batch, int64_t bsa, int64_t bsb, int64_t bsc, int64_t split_k, float* workspace,
+                               void* stream) {
     APTAI_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, "aptai_sgemm_f32: bad arguments");
+    APTAI_REQUIRE(split_k >= 1 && (split_k == 1 || workspace != nullptr), "aptai_sgemm_f32: split_k > 1 needs a workspace");
     SgemmArgs g;
+    memset(&g, 0, sizeof(g));
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
     g.bsa = bsa; g.bsb = bsb; g.bsc = bsc; g.M = (int)M; g.N = (int)N; g.K = (int)K; g.a_bf16 = a_bf16; g.accumulate = accumulate;
     g.alpha = alpha;
-    APTAI_LAUNCH(sgemm_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64), (unsigned)batch), dim3(256), 0,
-                 (hipStream_t)stream, g);
-    APTAI_CHECK_LAUNCH("sgemm_kernel");
+    g.ws = workspace;
+    long kchunk = (long)ceil_div(ceil_div(K, split_k), SG_BK) * SG_BK;      // slabs start on K-tile boundaries
+    g.split_k = (int)ceil_div(K, kchunk);
+    g.kchunk = kchunk;
+    const long ea = a_bf16 ? 8 : 4;                                         // elements per 16-byte load
+    const long esz = a_bf16 ? 2 : 4;
+    g.vec_a = ((uintptr_t)A % 16 == 0) && (bsa % ea == 0) &&
+              ((sak == 1 && sam % ea == 0) || (sam == 1 && !a_bf16 && sak % 4 == 0));
+    (void)esz;
+    g.vec_b = ((uintptr_t)B % 16 == 0) && (bsb % 4 == 0) && ((sbn == 1 && sbk % 4 == 0) || (sbk == 1 && sbn % 4 == 0));
+    APTAI_LAUNCH(sgemm_mfma_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64), (unsigned)(batch * g.split_k)),
+                 dim3(256), 0, (hipStream_t)stream, g);
+    APTAI_CHECK_LAUNCH("sgemm_mfma_kernel");
+    if (g.split_k > 1) {
+        APTAI_LAUNCH(sgemm_reduce_kernel, dim3(gridn(batch * M * N)), dim3(256), 0, (hipStream_t)stream, g, (int)batch);
+        APTAI_CHECK_LAUNCH("sgemm_reduce_kernel");
+    }
     return APTAI_OK;
 }
 
@@ -379,18 +493,19 @@ extern "C" int aptai_embed_bwd(const int32_t* ids, const float* dout, float* dem
 }
 
 extern "C" int aptai_xattn_softmax_fwd(const float* raw, const int32_t* phn_ids, float* energy, float* att, float* att_log,
-                                       int64_t* align, int64_t B, int64_t T, int64_t N, void* stream) {
+                                       int64_t* align, float* fs_rows, int64_t B, int64_t T, int64_t N, void* stream) {
     APTAI_REQUIRE(raw && phn_ids && energy && att && att_log && N > 0 && N <= 64, "aptai_xattn_softmax_fwd: bad arguments (N <= 64)");
+    APTAI_REQUIRE(fs_rows == nullptr || N <= 63, "aptai_xattn_softmax_fwd: the forward-sum rows hold at most 63 phoneme slots");
     APTAI_LAUNCH(xattn_softmax_fwd_kernel, dim3((unsigned)ceil_div(B * T * 64, 256)), dim3(256), 0, (hipStream_t)stream, raw, phn_ids,
-                 energy, att, att_log, align, (int)B, (int)T, (int)N);
+                 energy, att, att_log, align, fs_rows, (int)B, (int)T, (int)N);
     APTAI_CHECK_LAUNCH("xattn_softmax_fwd_kernel");
     return APTAI_OK;
 }
-extern "C" int aptai_xattn_softmax_bwd(const float* att, const float* att_log, const float* d_att, const float* d_attlog, float* d_raw,
-                                       int64_t rows, int64_t N, void* stream) {
+extern "C" int aptai_xattn_softmax_bwd(const float* att, const float* att_log, const float* d_att, const float* d_attlog,
+                                       int64_t ld_dattlog, float* d_raw, int64_t rows, int64_t N, void* stream) {
     APTAI_REQUIRE(att && att_log && d_raw && N > 0 && N <= 64, "aptai_xattn_softmax_bwd: bad arguments");
     APTAI_LAUNCH(xattn_softmax_bwd_kernel, dim3((unsigned)ceil_div(rows * 64, 256)), dim3(256), 0, (hipStream_t)stream, att, att_log,
-                 d_att, d_attlog, d_raw, (long)rows, (int)N);
+                 d_att, d_attlog, (long)(ld_dattlog > 0 ? ld_dattlog : N), d_raw, (long)rows, (int)N);
     APTAI_CHECK_LAUNCH("xattn_softmax_bwd_kernel");
     return APTAI_OK;
 }
@@ -413,20 +528,20 @@ extern "C" int aptai_layernorm_f32_bwd(const float* dy, const float* x, const fl
     return APTAI_OK;
 }
 
-extern "C" int aptai_lstm_fwd(const float* xproj, const float* whhT, const int32_t* lens, float* hout, float* gates, float* cstate,
+extern "C" int aptai_lstm_fwd_serial(const float* xproj, const float* whhT, const int32_t* lens, float* hout, float* gates, float* cstate,
                               int64_t B, int64_t Tp, int64_t T, int64_t hidden, void* stream) {
-    APTAI_REQUIRE(xproj && whhT && lens && hout, "aptai_lstm_fwd: null pointer");
-    APTAI_REQUIRE(hidden == HID, "aptai_lstm_fwd: built for hidden size 256");
-    APTAI_REQUIRE((gates == nullptr) == (cstate == nullptr), "aptai_lstm_fwd: gates and cstate go together");
+    APTAI_REQUIRE(xproj && whhT && lens && hout, "aptai_lstm_fwd_serial: null pointer");
+    APTAI_REQUIRE(hidden == HID, "aptai_lstm_fwd_serial: built for hidden size 256");
+    APTAI_REQUIRE((gates == nullptr) == (cstate == nullptr), "aptai_lstm_fwd_serial: gates and cstate go together");
     APTAI_LAUNCH(lstm_fwd_kernel, dim3((unsigned)B, 2), dim3(HID), 0, (hipStream_t)stream, xproj, whhT, lens, hout, gates, cstate,
                  (int)Tp, (int)T);
     APTAI_CHECK_LAUNCH("lstm_fwd_kernel");
     return APTAI_OK;
 }
-extern "C" int aptai_lstm_bwd(const float* dhout, const float* whh, const int32_t* lens, const float* gates, const float* cstate,
+extern "C" int aptai_lstm_bwd_serial(const float* dhout, const float* whh, const int32_t* lens, const float* gates, const float* cstate,
                               float* dgates, int64_t B, int64_t Tp, int64_t T, int64_t hidden, void* stream) {
-    APTAI_REQUIRE(dhout && whh && lens && gates && cstate && dgates, "aptai_lstm_bwd: null pointer");
-    APTAI_REQUIRE(hidden == HID, "aptai_lstm_bwd: built for hidden size 256");
+    APTAI_REQUIRE(dhout && whh && lens && gates && cstate && dgates, "aptai_lstm_bwd_serial: null pointer");
+    APTAI_REQUIRE(hidden == HID, "aptai_lstm_bwd_serial: built for hidden size 256");
     APTAI_LAUNCH(lstm_bwd_kernel, dim3((unsigned)B, 2), dim3(HID), 0, (hipStream_t)stream, dhout, whh, lens, gates, cstate, dgates,
                  (int)Tp, (int)T);
     APTAI_CHECK_LAUNCH("lstm_bwd_kernel");
@@ -467,9 +582,18 @@ extern "C" int aptai_dropout_f32(const float* x, float* y, int64_t n, float drop
     APTAI_CHECK_LAUNCH("drop32_kernel");
     return APTAI_OK;
 }
-extern "C" int aptai_colsum_f32(const float* x, int64_t ld, float* out, int64_t rows, int64_t N, void* stream) {
-    APTAI_REQUIRE(x && out && rows > 0 && N > 0, "aptai_colsum_f32: bad arguments");
-    APTAI_LAUNCH(colsum32_kernel, dim3((unsigned)ceil_div(N, 64)), dim3(64), 0, (hipStream_t)stream, x, (long)ld, out, (long)rows, (int)N);
-    APTAI_CHECK_LAUNCH("colsum32_kernel");
+extern "C" int64_t aptai_colsum_f32_workspace_bytes(int64_t N) { return (int64_t)CS_CHUNKS * N * 4; }
+extern "C" int aptai_colsum_f32(const float* x, int64_t ld, float* out, float* workspace, int64_t rows, int64_t N, void* stream) {
+    APTAI_REQUIRE(x && out && workspace && rows > 0 && N > 0, "aptai_colsum_f32: bad arguments");
+    long chunks = ceil_div(rows, 64);
+    if (chunks > CS_CHUNKS) chunks = CS_CHUNKS;
+    const long rpc = ceil_div(rows, chunks);
+    chunks = ceil_div(rows, rpc);
+    APTAI_LAUNCH(colsum32_part_kernel, dim3((unsigned)ceil_div(N, 64), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x, (long)ld,
+                 workspace, (long)rows, (int)N, rpc);
+    APTAI_CHECK_LAUNCH("colsum32_part_kernel");
+    APTAI_LAUNCH(colsum32_final_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out,
+                 (int)chunks, (int)N);
+    APTAI_CHECK_LAUNCH("colsum32_final_kernel");
     return APTAI_OK;
 }

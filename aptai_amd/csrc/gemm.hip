@@ -56,6 +56,7 @@ struct GemmArgs {
     int ktiles_per_split;
     long slab_stride;           // elements between split-K slabs (fp32 out only)
     int tiles_m, tiles_n;
+    int raster_gm;              // tile rows per raster group (raster2d); 0 = row-major walk
     // 2-level batching: blockIdx.y = outer * nb_inner + inner; element offsets per level
     int nb_inner;
     long sA[2], sB[2], sC[2], sBias[2], sR[2], sAux[2];
@@ -219,6 +220,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// 2-D rasterisation of a (remapped) tile index: groups of `gm` tile rows are walked row-fastest, then along N, so the blocks
+// that run TOGETHER on one XCD (its contiguous run of indices, ~64 resident tiles) touch gm A-panels and ~64/gm B-panels instead of
+// a few A-panels and EVERY B-panel: for [8192 x 768] x [3072 x 768]^T the row-major walk re-streamed the whole 4.7 MB weight
+// matrix past each XCD's 4 MB L2 once per row panel (7.4x the algorithmic bytes on the L2 fabric side, rocprofv3 FETCH_SIZE,
+// round 1).  gm = 0 keeps the row-major walk (APTAI_GEMM_RASTER=0, A/B).
+__device__ __forceinline__ void raster2d(int bid, int tiles_m, int tiles_n, int gm, int& tile_m, int& tile_n) {
+    if (gm <= 1) { tile_m = bid / tiles_n; tile_n = bid % tiles_n; return; }
+    const int group = gm * tiles_n;
+    const int first = (bid / group) * gm;
+    const int rows = tiles_m - first < gm ? tiles_m - first : gm;
+    const int r = bid % group;
+    tile_m = first + r % rows;
+    tile_n = r / rows;
+}
+
 // one BM_T x 128 output tile: `bid` is the (already remapped) tile index of problem g, `batch` < 0 = not batched.
 // BM_T = 128: wave tile 64 x 64, 2 blocks per CU.  BM_T = 64 (K-contiguous A only): wave tile 32 x 64, 24 KiB stages, 3 blocks
 // per CU = 768 slots - for [8192] x 768 outputs, whose 384 big tiles fill only 0.75 of one round of 512 slots while their 768
@@ -231,7 +247,8 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+    int tile_m, tile_n;
+    raster2d(bid, g.tiles_m, g.tiles_n, g.raster_gm, tile_m, tile_n);
     constexpr int NI = BM_T / 32;                       // 16-row MFMA tiles per wave
     constexpr int WM = BM_T / 2;                        // wave tile height
     constexpr int NA_IT = BM_T / 32;                    // staging instructions per thread for the A tile
@@ -700,7 +717,8 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+    int tile_m, tile_n;
+    raster2d(bid, g.tiles_m, g.tiles_n, g.raster_gm, tile_m, tile_n);
     const int m0 = tile_m * T2_BM, n0 = tile_n * T2_BN;
     if (gridDim.y > 1) {
         const int bo = blockIdx.y / g.nb_inner, bi = blockIdx.y % g.nb_inner;
@@ -976,7 +994,8 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tile_m = bid / g.tiles_n, tile_n = bid % g.tiles_n;
+    int tile_m, tile_n;
+    raster2d(bid, g.tiles_m, g.tiles_n, g.raster_gm, tile_m, tile_n);
     const int m0 = tile_m * T3_BM, n0 = tile_n * T3_BN;
     if (gridDim.y > 1) {
         const int bo = blockIdx.y / g.nb_inner, bi = blockIdx.y % g.nb_inner;
@@ -1190,6 +1209,14 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     g.alpha = d->alpha;
     g.tiles_m = (int)ceil_div(d->M, BM);
     g.tiles_n = (int)ceil_div(d->N, BN);
+    {
+        static int raster = -1;
+        if (raster < 0) {
+            const char* e = getenv("APTAI_GEMM_RASTER");
+            raster = e ? atoi(e) : 8;
+        }
+        g.raster_gm = raster;
+    }
     const int total_kt = g.K / BK;
     nsplit = d->split_k > 0 ? d->split_k : 1;
     if (nsplit > total_kt) nsplit = total_kt;

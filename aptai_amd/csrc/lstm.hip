@@ -1,0 +1,322 @@
+// BiLSTM(256 -> 256, one layer, packed sequences) of the Force_APTAI regression head (models/modules.py:195,204-206), forward
+// and backward through time, as COOPERATING workgroups (gfx950).
+//
+// The recurrence is sequential over T = 499 frames and tiny per frame (16 utterances x 256 x 1024 MACs per direction), so the
+// step latency is everything.  The first build ran one 256-thread block per (utterance, direction) and re-streamed the 1 MB
+// fp32 W_hh from L2 on every frame: 12 us per frame, 6 ms forward + 13.7 ms backward per training step (rocprofv3, round 2).
+// Here the 16 utterances of a batch group advance TOGETHER, and W_hh never moves:
+//   * a cluster = 16 workgroups per (batch group of 16 utterances, direction); workgroup k owns hidden units [16k, 16k+16)
+//     = 64 gate columns, whose W_hh slice (64 KB) lives in REGISTERS for the whole kernel as the B operand of
+//     v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: exact fp32, the M = 16 rows are the 16 utterances);
+//   * per frame every workgroup needs the whole h_{t-1} [16][256]: each publishes its [16][16] slice as 8-byte {tag, value}
+//     granules (one write-through store per lane) into a double-buffered exchange area and sweeps all 4096 granules of the
+//     previous frame until every tag matches (guide, Guideline 16 R2: the data is the flag, no fences, placement-independent);
+//   * backward: workgroup k forms the pre-activation gradients of its own 64 gate columns, multiplies them with its W_hh rows
+//     ([16 x 64] . [64 x 256]) and publishes the partial dh_{t-1} [16][256]; every workgroup sums the 16 partials of its own
+//     units in workgroup order (deterministic).
+// Tags count frames within one launch (1..T) and the exchange area is zeroed by a memset node ahead of every launch, so a
+// replayed hipGraph is safe.  Every spin is bounded; a timeout raises the status word at the end of the workspace.
+// All 16 workgroups of a cluster must be resident together: a launch holds at most 12 clusters = 192 workgroups of one wave
+// per SIMD on a 256-CU chip.
+#include "common.h"
+
+namespace {
+
+constexpr int LH = 256;                 // hidden size
+constexpr int LC_WG = 16;               // workgroups per cluster
+constexpr long LC_EX_GRANULES = 2L * 16 * 16 * 256;      // backward needs 2 parities x [dest 16][src 16][256]; forward 2 x 4096
+constexpr long LC_EX_BYTES = LC_EX_GRANULES * 8;        // 1 MiB per cluster
+constexpr int LC_MAX_BGROUPS = 6;       // batch groups (x 2 directions x 16 workgroups) per launch
+constexpr unsigned LC_SPIN_LIMIT = 1u << 22;
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+
+struct LstmArgs {
+    const float* xproj; const float* whh; const int* lens;
+    float* hout; float* gates; float* cstate;
+    const float* dhout; const float* gates_in; const float* cstate_in; float* dgates;
+    u64* ex; unsigned* status;
+    int B, Tp, T, bgroup0;
+};
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+template <int SRC>
+__device__ __forceinline__ float quad_bcast(float v) {                   // value of lane (quad base + SRC)
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), SRC * 0x55, 0xf, 0xf, true));
+}
+template <int SRC>
+__device__ __forceinline__ float quad_pick(const f32x4& acc, int slot) {  // register `slot` of lane (quad base + SRC)
+    const float v0 = quad_bcast<SRC>(acc[0]), v1 = quad_bcast<SRC>(acc[1]), v2 = quad_bcast<SRC>(acc[2]), v3 = quad_bcast<SRC>(acc[3]);
+    return slot == 0 ? v0 : slot == 1 ? v1 : slot == 2 ? v2 : v3;
+}
+__device__ __forceinline__ u64 granule(unsigned tag, float v) { return ((u64)tag << 32) | (u64)__float_as_uint(v); }
+
+// sweep N granules (stride `stride` u64 from `src`) until every tag equals `tag`; false on timeout
+template <int N>
+__device__ __forceinline__ bool sweep(const gu64* src, long stride, unsigned tag, u64 (&g)[N], unsigned* status) {
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            g[r] = __hip_atomic_load(src + r * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok &= (unsigned)(g[r] >> 32) == tag;
+        }
+        if (__all(ok)) return true;
+        if (spins > LC_SPIN_LIMIT) {
+            if ((threadIdx.x & 63) == 0) atomicExch(status, 1u);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// ================================================================================================ forward
+// grid = clusters x 16, 256 threads.  wave w, lane (j = lane & 15, q = lane >> 4): gate column j of the wave's n-tile =
+// (unit 16k + 4w + (j >> 2), gate j & 3); MFMA k index (q, ss) <-> hidden unit q*64 + ss; C rows = utterances 4q + reg.
+__global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) float hs[16 * LH];       // h_{t-1} as MFMA A image: [c 0..15][lane][4 floats]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cluster = blockIdx.x / LC_WG, k = blockIdx.x % LC_WG;
+    const int dir = cluster & 1, bg = a.bgroup0 + (cluster >> 1);
+    const int j = lane & 15, q = lane >> 4;
+    const int unit = k * 16 + wave * 4 + (j >> 2), gate = j & 3;
+    const int col = gate * LH + unit;
+
+    float w[64];                                                      // W_hh[col][q*64 .. q*64+63]: resident for the whole kernel
+    {
+        const float* wrow = a.whh + ((long)dir * 4 * LH + col) * LH + q * 64;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 v = *(const f32x4*)(wrow + 4 * c);
+            w[4 * c] = v[0]; w[4 * c + 1] = v[1]; w[4 * c + 2] = v[2]; w[4 * c + 3] = v[3];
+        }
+    }
+    int lenr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = bg * 16 + 4 * q + r;
+        int l = b < a.B ? a.lens[b] : 0;
+        lenr[r] = l < a.T ? l : a.T;
+    }
+    int maxlen = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int b = bg * 16 + i;
+        int l = b < a.B ? a.lens[b] : 0;
+        l = l < a.T ? l : a.T;
+        maxlen = l > maxlen ? l : maxlen;
+    }
+    const int myrow = 4 * q + gate, myb = bg * 16 + myrow;            // the (utterance, unit) this lane finalises
+    const int mylen = gate == 0 ? lenr[0] : gate == 1 ? lenr[1] : gate == 2 ? lenr[2] : lenr[3];
+    float c_st = 0.f, h_st = 0.f;
+    gu64* ex = (gu64*)(a.ex + (long)cluster * LC_EX_GRANULES);
+
+    for (int s = 0; s < maxlen; ++s) {
+        f32x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = bg * 16 + 4 * q + r;
+            const int t = dir ? lenr[r] - 1 - s : s;
+            acc[r] = s < lenr[r] ? a.xproj[(((long)b * a.Tp + t) * 2 + dir) * 4 * LH + col] : 0.f;
+        }
+        if (s > 0) {
+            // ---- gather h_{s-1}: granule (unit u, batch i) at u*16 + i; thread reads idx = r*256 + tid -> u = r*16 + (tid >> 4), i = tid & 15
+            u64 g[16];
+            sweep<16>(ex + ((s - 1) & 1) * 4096 + tid, 256, (unsigned)s, g, a.status);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // element (i, u): MFMA image word = c*256 + (qq*16 + i)*4 + e with qq = u >> 6, c = (u & 63) >> 2, e = u & 3
+                const int c = (r & 3) * 4 + wave, qq = r >> 2, e = (lane >> 4) & 3, i = lane & 15;
+                hs[c * 256 + (qq * 16 + i) * 4 + e] = __uint_as_float((unsigned)g[r]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x4 av = *(const f32x4*)&hs[c * 256 + lane * 4];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], w[4 * c], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], w[4 * c + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], w[4 * c + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], w[4 * c + 3], acc, 0, 0, 0);
+            }
+            __syncthreads();                                            // the image is free for the next frame's gather
+        }
+        // ---- the four gates of (utterance 4q + slot, unit) sit in the four lanes of the quad, register = slot: 4 x 4 transpose
+        const float gi = sigm(quad_pick<0>(acc, gate)), gf = sigm(quad_pick<1>(acc, gate)), gg = tanhf(quad_pick<2>(acc, gate)),
+                    go = sigm(quad_pick<3>(acc, gate));
+        const float c_new = gf * c_st + gi * gg;
+        const float h_new = go * tanhf(c_new);
+        const bool act = s < mylen;
+        if (act) { c_st = c_new; h_st = h_new; }
+        __hip_atomic_store(ex + (s & 1) * 4096 + unit * 16 + myrow, granule((unsigned)(s + 1), h_st), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        if (act) {
+            const int t = dir ? mylen - 1 - s : s;
+            const long row = (long)myb * a.Tp + t;
+            a.hout[row * 2 * LH + dir * LH + unit] = h_new;
+            if (a.gates) {
+                float* gp = a.gates + (row * 2 + dir) * 4 * LH + unit;
+                gp[0] = gi; gp[LH] = gf; gp[2 * LH] = gg; gp[3 * LH] = go;
+                a.cstate[(row * 2 + dir) * LH + unit] = c_new;
+            }
+        }
+    }
+    // frames beyond each utterance: zeros (pad_packed_sequence) for this workgroup's 16 units
+    for (int i = 0; i < 16; ++i) {
+        const int b = bg * 16 + i;
+        if (b >= a.B) break;
+        int l = a.lens[b];
+        l = l < a.T ? l : a.T;
+        for (int t = l + (tid >> 4); t < a.Tp; t += 16) a.hout[((long)b * a.Tp + t) * 2 * LH + dir * LH + k * 16 + (tid & 15)] = 0.f;
+    }
+}
+
+// ================================================================================================ backward through time
+// thread (eb = tid & 15, eu = tid >> 4) owns (utterance eb, unit 16k + eu) of the elementwise part; MFMA: A = the workgroup's
+// pre-activation gradients [16 utterances][64 gate columns] (k index (q, ss) <-> gate q, unit 16k + ss), B = W_hh rows of those
+// columns [64][256 units] in registers, wave w -> output units 64w .. 64w+63 (4 n-tiles = 4 destination workgroups).
+__global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) float dgs[16 * 64];      // A image: [c 0..3][lane][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cluster = blockIdx.x / LC_WG, k = blockIdx.x % LC_WG;
+    const int dir = cluster & 1, bg = a.bgroup0 + (cluster >> 1);
+    const int j = lane & 15, q = lane >> 4;
+    const int eb = tid & 15, eu = tid >> 4, unit = k * 16 + eu;
+    const int b = bg * 16 + eb;
+    int len = b < a.B ? a.lens[b] : 0;
+    len = len < a.T ? len : a.T;
+    int maxlen = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int bb = bg * 16 + i;
+        int l = bb < a.B ? a.lens[bb] : 0;
+        l = l < a.T ? l : a.T;
+        maxlen = l > maxlen ? l : maxlen;
+    }
+    float w[4][16];                                                   // W_hh[q*256 + 16k + ss][64w + 16nt + j]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ss = 0; ss < 16; ++ss)
+            w[nt][ss] = a.whh[((long)dir * 4 * LH + q * LH + k * 16 + ss) * LH + wave * 64 + nt * 16 + j];
+    gu64* ex = (gu64*)(a.ex + (long)cluster * LC_EX_GRANULES);
+    constexpr long PAR = 16L * 16 * 256;                              // granules per parity
+    float dc = 0.f;
+    for (int n = 0; n < maxlen; ++n) {
+        const int s = maxlen - 1 - n;
+        const bool act = s < len;
+        const int t = dir ? len - 1 - s : s;
+        const long row = (long)b * a.Tp + t;
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f, cprev = 0.f, dho = 0.f;
+        if (act) {
+            const float* gp = a.gates_in + (row * 2 + dir) * 4 * LH + unit;
+            gi = gp[0]; gf = gp[LH]; gg = gp[2 * LH]; go = gp[3 * LH];
+            c = a.cstate_in[(row * 2 + dir) * LH + unit];
+            if (s > 0) cprev = a.cstate_in[((row + (dir ? 1 : -1)) * 2 + dir) * LH + unit];
+            dho = a.dhout[row * 2 * LH + dir * LH + unit];
+        }
+        float dh_rec = 0.f;
+        if (n > 0) {
+            // partial sums of iteration n-1 for this workgroup's units: [src 16][unit_l 16][batch 16], thread = (eu, eb)
+            u64 g[16];
+            sweep<16>(ex + ((n - 1) & 1) * PAR + (long)k * 16 * 256 + tid, 256, (unsigned)n, g, a.status);
+#pragma unroll
+            for (int src = 0; src < 16; ++src) dh_rec += __uint_as_float((unsigned)g[src]);
+        }
+        float pi = 0.f, pf = 0.f, pg = 0.f, po = 0.f;
+        if (act) {
+            const float dh = dho + dh_rec;
+            const float tc = tanhf(c);
+            const float d_o = dh * tc;
+            dc += dh * go * (1.f - tc * tc);
+            const float d_i = dc * gg, d_g = dc * gi, d_f = dc * cprev;
+            pi = d_i * gi * (1.f - gi); pf = d_f * gf * (1.f - gf); pg = d_g * (1.f - gg * gg); po = d_o * go * (1.f - go);
+            dc = dc * gf;
+            float* dgp = a.dgates + (row * 2 + dir) * 4 * LH + unit;
+            dgp[0] = pi; dgp[LH] = pf; dgp[2 * LH] = pg; dgp[3 * LH] = po;
+        }
+        if (n + 1 < maxlen) {
+            // ---- A image: element (i = eb, kk = gate*16 + eu): word = c*256 + (gate*16 + eb)*4 + e, c = eu >> 2, e = eu & 3
+            const int base = (eu >> 2) * 256 + eb * 4 + (eu & 3);
+            dgs[base] = pi; dgs[base + 64] = pf; dgs[base + 128] = pg; dgs[base + 192] = po;
+            __syncthreads();
+            f32x4 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4)(0.f);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const f32x4 av = *(const f32x4*)&dgs[cc * 256 + lane * 4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], w[nt][4 * cc + e], acc[nt], 0, 0, 0);
+            }
+            __syncthreads();
+            // ---- publish the partial dh_{t-1}: element (utterance 4q + r, unit 64w + 16nt + j) -> dest 4w + nt, unit_l j
+            gu64* out = ex + (n & 1) * PAR;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(out + (((long)(wave * 4 + nt) * 16 + k) * 16 + j) * 16 + 4 * q + r,
+                                       granule((unsigned)(n + 1), acc[nt][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // frames beyond each utterance: zero pre-activation gradients for this workgroup's 64 gate columns
+    for (int i = 0; i < 16; ++i) {
+        const int bb = bg * 16 + i;
+        if (bb >= a.B) break;
+        int l = a.lens[bb];
+        l = l < a.T ? l : a.T;
+        for (int t = l + (tid >> 6); t < a.Tp; t += 4) {
+            float* dgp = a.dgates + (((long)bb * a.Tp + t) * 2 + dir) * 4 * LH + (lane >> 4) * LH + k * 16 + (lane & 15);
+            *dgp = 0.f;
+        }
+    }
+}
+
+int launch_cluster(bool backward, LstmArgs a, void* workspace, int64_t B, hipStream_t stream) {
+    const int nb = (int)ceil_div(B, 16);
+    a.status = (unsigned*)workspace;                       // first 256 bytes: status word; the exchange areas follow
+    for (int bg0 = 0; bg0 < nb; bg0 += LC_MAX_BGROUPS) {
+        const int n = nb - bg0 < LC_MAX_BGROUPS ? nb - bg0 : LC_MAX_BGROUPS;
+        a.bgroup0 = bg0;
+        a.ex = (u64*)((char*)workspace + 256 + (long)bg0 * 2 * LC_EX_BYTES);
+        // tags restart at 1 in every launch: the exchange area must not hold a previous launch's granules
+        if (hipMemsetAsync(a.ex, 0, (size_t)n * 2 * LC_EX_BYTES, stream) != hipSuccess)
+            APTAI_FAIL(APTAI_ERR_LAUNCH, "aptai_lstm: hipMemsetAsync of the exchange area failed");
+        if (backward) APTAI_LAUNCH(lstm_cluster_bwd_kernel, dim3((unsigned)(n * 2 * LC_WG)), dim3(256), 0, stream, a);
+        else APTAI_LAUNCH(lstm_cluster_fwd_kernel, dim3((unsigned)(n * 2 * LC_WG)), dim3(256), 0, stream, a);
+        APTAI_CHECK_LAUNCH(backward ? "lstm_cluster_bwd_kernel" : "lstm_cluster_fwd_kernel");
+    }
+    return APTAI_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t aptai_lstm_workspace_bytes(int64_t B) { return ceil_div(B, 16) * 2 * LC_EX_BYTES + 256; }
+
+extern "C" int aptai_lstm_fwd(const float* xproj, const float* whh, const int32_t* lens, float* hout, float* gates, float* cstate,
+                              void* workspace, int64_t B, int64_t Tp, int64_t T, int64_t hidden, void* stream) {
+    APTAI_REQUIRE(xproj && whh && lens && hout && workspace, "aptai_lstm_fwd: null pointer");
+    APTAI_REQUIRE(hidden == LH, "aptai_lstm_fwd: built for hidden size 256");
+    APTAI_REQUIRE((gates == nullptr) == (cstate == nullptr), "aptai_lstm_fwd: gates and cstate go together");
+    APTAI_REQUIRE(B > 0 && T > 0 && Tp >= T, "aptai_lstm_fwd: bad sizes");
+    APTAI_REQUIRE((uintptr_t)whh % 16 == 0 && (uintptr_t)workspace % 16 == 0, "aptai_lstm_fwd: whh / workspace must be 16-byte aligned");
+    LstmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xproj = xproj; a.whh = whh; a.lens = lens; a.hout = hout; a.gates = gates; a.cstate = cstate;
+    a.B = (int)B; a.Tp = (int)Tp; a.T = (int)T;
+    return launch_cluster(false, a, workspace, B, (hipStream_t)stream);
+}
+
+extern "C" int aptai_lstm_bwd(const float* dhout, const float* whh, const int32_t* lens, const float* gates, const float* cstate,
+                              float* dgates, void* workspace, int64_t B, int64_t Tp, int64_t T, int64_t hidden, void* stream) {
+    APTAI_REQUIRE(dhout && whh && lens && gates && cstate && dgates && workspace, "aptai_lstm_bwd: null pointer");
+    APTAI_REQUIRE(hidden == LH, "aptai_lstm_bwd: built for hidden size 256");
+    APTAI_REQUIRE(B > 0 && T > 0 && Tp >= T, "aptai_lstm_bwd: bad sizes");
+    LstmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dhout = dhout; a.whh = whh; a.lens = lens; a.gates_in = gates; a.cstate_in = cstate; a.dgates = dgates;
+    a.B = (int)B; a.Tp = (int)Tp; a.T = (int)T;
+    return launch_cluster(true, a, workspace, B, (hipStream_t)stream);
+}

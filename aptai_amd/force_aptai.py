@@ -47,16 +47,17 @@ class _ForceHeadsFn(torch.autograd.Function):
         ops.linear_f32(s.fhd, q_w, q_b, out=q, ldc=256)
         s.k = ops.linear_f32(s.phn, k_w, k_b)                                                                  # [B*60][128]
         raw = ops.sgemm(q, 256, 1, s.k, 1, 128, Tp, _NPHN, 128, batch=B, bsa=Tp * 256, bsb=_NPHN * 128, bsc=Tp * _NPHN)
-        s.energy, s.att, s.att_log, s.align = ops.xattn_softmax_fwd(raw, st.ids, B, Tp, _NPHN)
+        # forward-sum (CTC) input rows [blank = -1 | att_log | 0], written by the same kernel
+        s.pad = torch.empty((M, 64), device=dev, dtype=torch.float32)
+        s.energy, s.att, s.att_log, s.align = ops.xattn_softmax_fwd(raw, st.ids, B, Tp, _NPHN, fs_rows=s.pad)
         ops.sgemm(s.att, _NPHN, 1, s.k, 128, 1, Tp, 128, _NPHN, out=s.cat, ldc=256, batch=B, bsa=Tp * _NPHN, bsb=_NPHN * 128,
                   bsc=Tp * 256)
         s.att_out, s.lm, s.lr = ops.layernorm_f32_fwd(s.cat, ln_w, ln_b)
         s.wih = torch.cat([wih0, wih1]).contiguous()                                                          # [2048][256]
         bsum = torch.cat([bih0 + bhh0, bih1 + bhh1]).contiguous()
         xproj = ops.linear_f32(s.att_out, s.wih, bsum)                                                         # [M][2048]
-        whhT = torch.stack([whh0.t().contiguous(), whh1.t().contiguous()]).contiguous()                       # [2][256][1024]
         s.whh = torch.stack([whh0, whh1]).contiguous()                                                         # [2][1024][256]
-        s.hout, s.gates, s.cst = ops.lstm_fwd(xproj, whhT, st.rnn_lens, B, Tp, T)
+        s.hout, s.gates, s.cst = ops.lstm_fwd(xproj, s.whh, st.rnn_lens, B, Tp, T)
         h1 = ops.linear_f32(s.hout, l0_w, l0_b)
         s.h1a = ops.tanh_dropout_fwd(h1, st.p_rnn, _seed(st.seed, 3))
         tv_raw = ops.linear_f32(s.h1a, l3_w, l3_b)                                                             # [M][9]
@@ -67,10 +68,6 @@ class _ForceHeadsFn(torch.autograd.Function):
         s.dummy_phn = torch.zeros((B, T), device=dev, dtype=torch.int64)
         s.sc, _ = ops.aptai_loss_fwd(s.tvs, st.tv_tgt, s.dummy_logits, 1, Tp, s.dummy_phn, B, T, n_tv, 1, 1.0, 0.0, want_pred=False)
         # forward-sum (CTC) alignment loss on [blank=-1 | att_log]
-        s.pad = torch.empty((M, 64), device=dev, dtype=torch.float32)
-        s.pad[:, 0] = -1.0
-        s.pad[:, 1:1 + _NPHN] = s.att_log
-        s.pad[:, 1 + _NPHN:] = 0.0
         s.fs_loss, s.nll, _, s.alpha = ops.ctc_fwd(s.pad, 64, Tp, st.fs_targets, st.frame_lens, st.text_lens, B, T, _NPHN + 1,
                                                    blank=0, reduction="mean", zero_infinity=True, vocab_sizes_i32=st.vocab_sizes,
                                                    want_log_probs=False)
@@ -120,8 +117,7 @@ class _ForceHeadsFn(torch.autograd.Function):
         dpad = ops.ctc_bwd(s.pad, 64, Tp, st.fs_targets, st.frame_lens, st.text_lens, B, T, _NPHN + 1, s.alpha, s.nll,
                            (0.6 * gl).contiguous(), blank=0, reduction="mean", zero_infinity=True, vocab_sizes_i32=st.vocab_sizes,
                            ldd=64, out_dtype=torch.float32)
-        d_attlog = dpad[:, 1:1 + _NPHN].contiguous()
-        d_raw = ops.xattn_softmax_bwd(s.att, s.att_log, d_att, d_attlog)
+        d_raw = ops.xattn_softmax_bwd(s.att, s.att_log, d_att, dpad[:, 1:], ld_dattlog=64)     # columns 1..60 of the 64-float rows, in place
         dq = dcat[:, 128:].contiguous()
         ops.sgemm(d_raw, _NPHN, 1, s.k, 128, 1, Tp, 128, _NPHN, out=dq, ldc=128, accumulate=True, batch=B, bsa=Tp * _NPHN,
                   bsb=_NPHN * 128, bsc=Tp * 128)
@@ -180,35 +176,39 @@ class Force_APTAI(nn.Module):
 
     # ------------------------------------------------------------------ shared body
     def _run(self, audio_inputs, audio_lengths, tv_targets=None, phn_pred_list=None, _ac_override=None):
-        emb = self.w2v2_pr.get_embeddings(audio_inputs, audio_lengths)
-        out = emb['_out']
+        """Encoder (inference) -> decode -> heads.  Nothing in here synchronises host and device: the best-path decode, the
+        phoneme slots, every length vector and the alignment read-out stay on the device; `_lists` makes the Python lists the
+        reference returns with one round of transfers at the very end."""
+        pr = self.w2v2_pr
+        pr.eval()                                                      # models/w2v2_pr.py:125: the recogniser always runs in eval mode
+        with torch.no_grad():
+            lens1d = audio_lengths.reshape(-1)
+            out, _ = pr._logits_eval(audio_inputs, lens1d[:, None])
         g = out._geom
         dev = out._flat_last.device
         ac = out._flat_last if _ac_override is None else _ac_override      # test hook: heads on given embeddings
+        frame_lens = pr.wav2vec2._get_feat_extract_output_lengths(lens1d.to(dev)).to(torch.int32).contiguous()
         if phn_pred_list is None:
-            phn_pred_list = emb['phn_pred_seq_idx']
-        frame_seq_lens = emb['frame_seq_lens'].reshape(-1).tolist()
-        phn_seq_lens = [len(l) for l in phn_pred_list]
-        padded = []
-        for lst in phn_pred_list:
-            assert len(lst) < self.max_phn_seq_len, 'Need longer max phoneme sequence length.'
-            padded.append(np.pad(np.asarray(lst, dtype=np.int64), (0, self.max_phn_seq_len - len(lst)), mode='constant'))
-        ids = torch.tensor(np.array(padded), dtype=torch.int32, device=dev)
+            ids, nlen = pr._decode_device(out, self.max_phn_seq_len)      # int32 [B][60] zero-padded, int32 [B]
+        else:
+            padded = []
+            for lst in phn_pred_list:
+                assert len(lst) < self.max_phn_seq_len, 'Need longer max phoneme sequence length.'
+                padded.append(np.pad(np.asarray(lst, dtype=np.int64), (0, self.max_phn_seq_len - len(lst)), mode='constant'))
+            ids = torch.tensor(np.array(padded), dtype=torch.int32, device=dev)
+            nlen = torch.tensor([len(l) for l in phn_pred_list], dtype=torch.int32, device=dev)
         tr = self.training
         n_tv = self.rnn.linear[3].weight.shape[0]
         if tv_targets is None:
             tv_targets = torch.full((g.B, g.T, n_tv), -100.0, device=dev)
-        fs_targets = torch.arange(1, _NPHN + 1, dtype=torch.int32, device=dev)[None, :].repeat(g.B, 1).contiguous()
+        consts = self._consts(g.B, dev)
         # models/modules.py:209-212: the batch-1 branch runs the LSTM unpacked over ALL frames
-        rnn_lens = [g.T] if g.B == 1 else frame_seq_lens
+        rnn_lens = consts["full_T"](g.T) if g.B == 1 else frame_lens
         st = SimpleNamespace(g=g, ids=ids, pe=self.pe_phn.pe.reshape(_NPHN, -1).contiguous(), taps=self.tv_lowpass.taps(),
                              p_hid=self.hidden_drop if tr else 0.0, p_rnn=self.rnn_drop if tr else 0.0,
-                             seed=_seed(self.w2v2_pr.wav2vec2.base_seed, self.w2v2_pr.wav2vec2._step, 4242),
-                             tv_tgt=tv_targets.contiguous(), fs_targets=fs_targets,
-                             frame_lens=torch.tensor(frame_seq_lens, dtype=torch.int32, device=dev),
-                             rnn_lens=torch.tensor(rnn_lens, dtype=torch.int32, device=dev),
-                             text_lens=torch.tensor(phn_seq_lens, dtype=torch.int32, device=dev),
-                             vocab_sizes=torch.tensor([n + 1 for n in phn_seq_lens], dtype=torch.int32, device=dev))
+                             seed=_seed(pr.wav2vec2.base_seed, pr.wav2vec2._step, 4242),
+                             tv_tgt=tv_targets.contiguous(), fs_targets=consts["fs_targets"], frame_lens=frame_lens, rnn_lens=rnn_lens,
+                             text_lens=nlen, vocab_sizes=nlen + 1)
         if getattr(self, "dp_loss_norm", None) is not None and tr:
             # the TV loss is a masked mean over the batch (models/force_aptai.py:137-141); the alignment and CTC terms are
             # means over utterances, which equal-sized shards already average exactly
@@ -221,13 +221,44 @@ class Force_APTAI(nn.Module):
              lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse, self.rnn.linear[0].weight,
              self.rnn.linear[0].bias, self.rnn.linear[3].weight, self.rnn.linear[3].bias)
         res = _ForceHeadsFn.apply(ac, st, *P)
-        return res, g, phn_pred_list, frame_seq_lens, phn_seq_lens, ids
+        return res, g, (ids, nlen, frame_lens, phn_pred_list)
+
+    def _consts(self, B, dev):
+        """Batch-size dependent constants (forward-sum targets 1..60, the all-frames length of the batch-1 branch)."""
+        key = (B, str(dev))
+        c = getattr(self, "_const_cache", {}).get(key)
+        if c is None:
+            full = {}
+
+            def full_T(T):
+                if T not in full:
+                    full[T] = torch.full((B,), T, dtype=torch.int32, device=dev)
+                return full[T]
+            c = {"fs_targets": torch.arange(1, _NPHN + 1, dtype=torch.int32, device=dev)[None, :].repeat(B, 1).contiguous(),
+                 "full_T": full_T}
+            self._const_cache = dict(getattr(self, "_const_cache", {}))
+            self._const_cache[key] = c
+        return c
+
+    def _lists(self, dec):
+        """Host views of the decode: (decoded id lists, frame lengths, decoded lengths, phoneme table) - the step's only
+        device->host transfers."""
+        ids, nlen, frame_lens, given = dec
+        fl = [int(v) for v in frame_lens.cpu().tolist()]
+        table = ids.cpu().numpy()
+        n = [int(v) for v in nlen.cpu().tolist()]
+        if given is None:
+            # models/force_aptai.py:111 (checked once the lengths are on the host; the device decode filled 60 slots at most)
+            assert all(v < self.max_phn_seq_len for v in n), 'Need longer max phoneme sequence length.'
+            given = [table[b, :n[b]].astype(np.int64) for b in range(len(n))]
+        return given, fl, n, table
 
     def forward(self, epoch, audio_inputs, audio_lengths, phoneme_labels, phn_frames_49hz, LA, LP, JA, TTCL, TTCD, TMCL, TMCD,
                 TBCL, TBCD, _phn_pred_list=None, _ac_override=None):
         tv_targets = torch.stack([LA, LP, JA, TTCL, TTCD, TMCL, TMCD, TBCL, TBCD], dim=-1).float()
-        res, g, phn_pred_list, frame_seq_lens, _, _ = self._run(audio_inputs, audio_lengths, tv_targets, _phn_pred_list, _ac_override)
+        res, g, dec = self._run(audio_inputs, audio_lengths, tv_targets, _phn_pred_list, _ac_override)
         loss, tv_loss, align_loss, tvs, frame_phns = res[:5]
+        phn_pred_list, frame_seq_lens, _, _ = self._lists(dec)
         fp = frame_phns.cpu().numpy()                                  # ONE transfer (reference: B*T .cpu() calls)
         pred_frame_phns = [fp[b, :frame_seq_lens[b]].tolist() for b in range(g.B)]
         return {'loss': loss, 'tv_loss': tv_loss, 'align_loss': align_loss, 'tvs_pred': tvs,
@@ -248,7 +279,8 @@ class Force_APTAI(nn.Module):
         self.eval()
         with torch.no_grad():
             wav_input, wav_len = self._wav(wav)
-            res, g, _, frame_seq_lens, phn_seq_lens, _ = self._run(wav_input, wav_len.reshape(-1))
+            res, g, dec = self._run(wav_input, wav_len.reshape(-1))
+            _, frame_seq_lens, phn_seq_lens, _ = self._lists(dec)
             att = res[5].view(g.B, g.Tp, _NPHN)[0]
             return {'alignment': att[0:frame_seq_lens[0], 0:phn_seq_lens[0]].permute(1, 0).cpu().numpy()}
 
@@ -257,11 +289,11 @@ class Force_APTAI(nn.Module):
         self.eval()
         with torch.no_grad():
             wav_input, wav_len = self._wav(wav)
-            res, g, phn_pred_list, frame_seq_lens, _, ids = self._run(wav_input, wav_len.reshape(-1))
+            res, g, dec = self._run(wav_input, wav_len.reshape(-1))
+            phn_pred_list, frame_seq_lens, _, table = self._lists(dec)
             tvs_out = res[3].squeeze(dim=0).cpu().numpy()
             tvs_pred_dict = {n: [row[i] for row in tvs_out] for i, n in enumerate(TV_NAMES)}
             align = res[8].view(g.B, g.Tp)[0, :g.T].cpu().numpy()
-            table = ids[0].cpu().numpy()
-            return {'tvs_pred': tvs_pred_dict, 'pred_frame_phns': [int(table[a]) for a in align],
+            return {'tvs_pred': tvs_pred_dict, 'pred_frame_phns': [int(table[0][a]) for a in align],
                     'pred_ctc_phn_seq': phn_pred_list, 'hidden_alignment': res[6].view(g.B, g.Tp, -1)[:, :g.T],
                     'hidden_tvs': res[7].view(g.B, g.Tp, -1)[:, :g.T]}

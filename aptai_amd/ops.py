@@ -472,8 +472,9 @@ _REDUCTION = {"none": 0, "mean": 1, "sum": 2}
 
 
 def ctc_fwd(logits, ldl, rows_per_b, targets_i32, input_lens_i32, target_lens_i32, B, T, V, *, blank=0, reduction="mean",
-            zero_infinity=True, vocab_sizes_i32=None, want_log_probs=True):
-    """Returns (loss scalar tensor, nll [B], log_probs (T,B,V) | None, alpha workspace)."""
+            zero_infinity=True, vocab_sizes_i32=None, want_log_probs=True, want_beta=None):
+    """Returns (loss scalar tensor, nll [B], log_probs (T,B,V) | None, workspace [alpha | beta | per-state log-probs]).
+    want_beta (default: when gradients are enabled) also runs the beta recursion, beside alpha in the same launch."""
     _dev(logits, targets_i32, input_lens_i32, target_lens_i32, vocab_sizes_i32)
     dev = logits.device
     ldt = targets_i32.shape[1]
@@ -481,9 +482,12 @@ def ctc_fwd(logits, ldl, rows_per_b, targets_i32, input_lens_i32, target_lens_i3
     nll = torch.empty(B, device=dev, dtype=torch.float32)
     loss = torch.zeros(1, device=dev, dtype=torch.float32)
     lp = torch.empty((T, B, V), device=dev, dtype=torch.float32) if want_log_probs else None
+    if want_beta is None:
+        want_beta = True
     _lib.call("aptai_ctc_fwd", logits.data_ptr(), ldl, rows_per_b, targets_i32.data_ptr(), ldt, input_lens_i32.data_ptr(),
               target_lens_i32.data_ptr(), _ptr(vocab_sizes_i32), B, T, V, blank, _REDUCTION[reduction], int(zero_infinity),
-              _ptr(lp), alpha.data_ptr(), nll.data_ptr(), loss.data_ptr(), _stream())
+              _ptr(lp), alpha.data_ptr(), nll.data_ptr(), loss.data_ptr(), int(want_beta), _stream())
+    alpha._beta_ready = bool(want_beta)
     return loss, nll, lp, alpha
 
 
@@ -494,21 +498,51 @@ def ctc_bwd(logits, ldl, rows_per_b, targets_i32, input_lens_i32, target_lens_i3
     _lib.call("aptai_ctc_bwd", logits.data_ptr(), ldl, rows_per_b, targets_i32.data_ptr(), targets_i32.shape[1],
               input_lens_i32.data_ptr(), target_lens_i32.data_ptr(), _ptr(vocab_sizes_i32), B, T, V, blank, _REDUCTION[reduction],
               int(zero_infinity), alpha.data_ptr(), nll.data_ptr(), _ptr(grad_out), extra_scale, d.data_ptr(), ldd,
-              int(out_dtype == torch.bfloat16), _stream())
+              int(out_dtype == torch.bfloat16), int(getattr(alpha, "_beta_ready", False)), _stream())
     return d
 
 
+def ctc_greedy_decode(logits, ldl, rows_per_b, B, T, V, blank, max_n):
+    """Device best-path decode: (ids int32 [B][max_n] zero-padded, n int32 [B]) - see aptai_ctc_greedy_decode."""
+    _dev(logits)
+    ids = torch.empty((B, max_n), device=logits.device, dtype=torch.int32)
+    n = torch.empty(B, device=logits.device, dtype=torch.int32)
+    _lib.call("aptai_ctc_greedy_decode", logits.data_ptr(), ldl, rows_per_b, B, T, V, blank, ids.data_ptr(), max_n, n.data_ptr(), _stream())
+    return ids, n
+
+
 # ----------------------------------------------------------------------------- Force_APTAI heads (fp32)
+_SCRATCH32 = {}
+
+
+def _scratch_f32(key, numel: int, device) -> torch.Tensor:
+    """Persistent fp32 scratch per (purpose, device): split-K slabs and column-sum partials of the fp32 heads (stream-ordered
+    reuse: every consumer of a scratch runs on the launch stream right after its producer)."""
+    k = (key, str(device))
+    t = _SCRATCH32.get(k)
+    if t is None or t.numel() < numel:
+        t = torch.empty(max(int(numel), 16), device=device, dtype=torch.float32)
+        _SCRATCH32[k] = t
+    return t
+
+
 def sgemm(a, sam, sak, b, sbk, sbn, M, N, K, *, out=None, ldc=None, bias=None, alpha=1.0, accumulate=False, batch=1, bsa=0, bsb=0,
-          bsc=0):
-    """C[m][n] (+)= alpha * sum_k A(m,k) B(k,n) + bias[n] with explicit element strides (see aptai_sgemm_f32)."""
+          bsc=0, split_k=None):
+    """C[m][n] (+)= alpha * sum_k A(m,k) B(k,n) + bias[n] with explicit element strides (see aptai_sgemm_f32).
+    split_k=None picks the K split that fills the chip for gradient-shaped problems (small M x N, long K)."""
     _dev(a, b, out, bias)
     if out is None:
         out = torch.empty((batch * M, N) if batch > 1 else (M, N), device=a.device, dtype=torch.float32)
         if batch > 1 and bsc == 0:
             bsc = M * N
+    if split_k is None:
+        tiles = ((M + 63) // 64) * ((N + 63) // 64) * batch
+        split_k = 1 if (tiles >= 256 or K < 1024) else max(1, min(K // 256, 512 // tiles))
+    ws = None
+    if split_k > 1:
+        ws = _scratch_f32("sgemm", batch * split_k * M * N, a.device)
     _lib.call("aptai_sgemm_f32", a.data_ptr(), int(a.dtype == torch.bfloat16), sam, sak, b.data_ptr(), sbk, sbn, out.data_ptr(),
-              ldc if ldc else N, _ptr(bias), alpha, int(accumulate), M, N, K, batch, bsa, bsb, bsc, _stream())
+              ldc if ldc else N, _ptr(bias), alpha, int(accumulate), M, N, K, batch, bsa, bsb, bsc, split_k, _ptr(ws), _stream())
     return out
 
 
@@ -533,20 +567,22 @@ def embed_bwd(ids_i32, dout, vocab, p, seed):
     return demb
 
 
-def xattn_softmax_fwd(raw, ids_i32, B, T, N):
+def xattn_softmax_fwd(raw, ids_i32, B, T, N, fs_rows=None):
+    """fs_rows (optional [B*T][64] fp32): also writes the forward-sum CTC input rows [-1 | att_log | 0]."""
     dev = raw.device
     energy, att, att_log = (torch.empty((B * T, N), device=dev, dtype=torch.float32) for _ in range(3))
     align = torch.empty((B, T), device=dev, dtype=torch.int64)
     _lib.call("aptai_xattn_softmax_fwd", raw.data_ptr(), ids_i32.data_ptr(), energy.data_ptr(), att.data_ptr(), att_log.data_ptr(),
-              align.data_ptr(), B, T, N, _stream())
+              align.data_ptr(), _ptr(fs_rows), B, T, N, _stream())
     return energy, att, att_log, align
 
 
-def xattn_softmax_bwd(att, att_log, d_att, d_attlog):
+def xattn_softmax_bwd(att, att_log, d_att, d_attlog, ld_dattlog=0):
+    """d_attlog may be a strided view (e.g. columns 1..N of the 64-float forward-sum gradient rows: pass ld_dattlog=64)."""
     rows, N = att.shape
     d_raw = torch.empty_like(att)
-    _lib.call("aptai_xattn_softmax_bwd", att.data_ptr(), att_log.data_ptr(), _ptr(d_att), _ptr(d_attlog), d_raw.data_ptr(), rows, N,
-              _stream())
+    _lib.call("aptai_xattn_softmax_bwd", att.data_ptr(), att_log.data_ptr(), _ptr(d_att), _ptr(d_attlog), ld_dattlog, d_raw.data_ptr(),
+              rows, N, _stream())
     return d_raw
 
 
@@ -570,19 +606,62 @@ def layernorm_f32_bwd(dy, x, mean, rstd, gamma):
     return dx, dg, db
 
 
-def lstm_fwd(xproj, whhT, lens_i32, B, Tp, T, save=True):
+_LSTM_WS = {}
+
+
+def _lstm_workspace(B: int, device) -> torch.Tensor:
+    """Exchange area of the cooperating LSTM workgroups (zeroed once here; every launch re-zeroes what it uses) + status word."""
+    n = _lib.lib().aptai_lstm_workspace_bytes(B)
+    key = str(device)
+    ws = _LSTM_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.zeros(n, device=device, dtype=torch.uint8)
+        _LSTM_WS[key] = ws
+    return ws
+
+
+def lstm_status(device) -> int:
+    """Non-zero if a bounded wait of the cooperating LSTM kernels ever timed out on this device (synchronises)."""
+    ws = _LSTM_WS.get(str(device))
+    return 0 if ws is None else int(ws[:256].view(torch.int32)[0].item())
+
+
+def lstm_fwd(xproj, whh, lens_i32, B, Tp, T, save=True):
+    """whh [2][1024][256] (weight_hh_l0 | weight_hh_l0_reverse).  Returns (hout [B*Tp][512], gates, cstate)."""
+    _dev(xproj, whh, lens_i32)
     dev = xproj.device
     hout = torch.empty((B * Tp, 512), device=dev, dtype=torch.float32)
-    gates = torch.zeros((B * Tp, 2048), device=dev, dtype=torch.float32) if save else None
-    cst = torch.zeros((B * Tp, 512), device=dev, dtype=torch.float32) if save else None
-    _lib.call("aptai_lstm_fwd", xproj.data_ptr(), whhT.data_ptr(), lens_i32.data_ptr(), hout.data_ptr(), _ptr(gates), _ptr(cst), B, Tp,
-              T, 256, _stream())
+    gates = torch.empty((B * Tp, 2048), device=dev, dtype=torch.float32) if save else None
+    cst = torch.empty((B * Tp, 512), device=dev, dtype=torch.float32) if save else None
+    ws = _lstm_workspace(B, dev)
+    _lib.call("aptai_lstm_fwd", xproj.data_ptr(), whh.data_ptr(), lens_i32.data_ptr(), hout.data_ptr(), _ptr(gates), _ptr(cst),
+              ws.data_ptr(), B, Tp, T, 256, _stream())
     return hout, gates, cst
 
 
 def lstm_bwd(dhout, whh, lens_i32, gates, cst, B, Tp, T):
+    _dev(dhout, whh, lens_i32, gates, cst)
     dgates = torch.empty_like(gates)
+    ws = _lstm_workspace(B, dhout.device)
     _lib.call("aptai_lstm_bwd", dhout.data_ptr(), whh.data_ptr(), lens_i32.data_ptr(), gates.data_ptr(), cst.data_ptr(),
+              dgates.data_ptr(), ws.data_ptr(), B, Tp, T, 256, _stream())
+    return dgates
+
+
+def lstm_fwd_serial(xproj, whhT, lens_i32, B, Tp, T, save=True):
+    """One block per (utterance, direction): cross-check of lstm_fwd (aptai_lstm_fwd_serial); whhT [2][256][1024]."""
+    dev = xproj.device
+    hout = torch.empty((B * Tp, 512), device=dev, dtype=torch.float32)
+    gates = torch.zeros((B * Tp, 2048), device=dev, dtype=torch.float32) if save else None
+    cst = torch.zeros((B * Tp, 512), device=dev, dtype=torch.float32) if save else None
+    _lib.call("aptai_lstm_fwd_serial", xproj.data_ptr(), whhT.data_ptr(), lens_i32.data_ptr(), hout.data_ptr(), _ptr(gates), _ptr(cst),
+              B, Tp, T, 256, _stream())
+    return hout, gates, cst
+
+
+def lstm_bwd_serial(dhout, whh, lens_i32, gates, cst, B, Tp, T):
+    dgates = torch.empty_like(gates)
+    _lib.call("aptai_lstm_bwd_serial", dhout.data_ptr(), whh.data_ptr(), lens_i32.data_ptr(), gates.data_ptr(), cst.data_ptr(),
               dgates.data_ptr(), B, Tp, T, 256, _stream())
     return dgates
 
@@ -615,5 +694,6 @@ def dropout_f32(x, p, seed):
 
 def colsum_f32(x, rows, N, ld=None):
     out = torch.empty(N, device=x.device, dtype=torch.float32)
-    _lib.call("aptai_colsum_f32", x.data_ptr(), ld if ld else x.stride(0), out.data_ptr(), rows, N, _stream())
+    ws = _scratch_f32("colsum", 64 * N, x.device)
+    _lib.call("aptai_colsum_f32", x.data_ptr(), ld if ld else x.stride(0), out.data_ptr(), ws.data_ptr(), rows, N, _stream())
     return out

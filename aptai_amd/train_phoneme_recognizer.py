@@ -132,8 +132,13 @@ def train(cfg, model, optimizer, lr_scheduler, vocab, train_dataloader, valid_da
 
 
 def _decode(model, outputs) -> list:
-    """Stand-in for `_ctc_decode(vocab, phoneme_logits)` (utility.py:448-471): best path over all frames of the batch-1 logits."""
-    return [int(i) for i in model._decode(outputs["phoneme_logits"])[0]]
+    """Stand-in for `_ctc_decode(vocab, phoneme_logits)` (utility.py:448-471): best path over all frames of the batch-1 logits
+    (the device decode kernel reads the fp32 logits the forward just produced)."""
+    lg = outputs["phoneme_logits"].float().contiguous()
+    B, T, V = lg.shape
+    from . import ops
+    ids, n = ops.ctc_greedy_decode(lg, V, T, B, T, V, model._blank(), T)
+    return [int(i) for i in ids[0, :int(n[0])].cpu().numpy()]
 
 
 def validate(model, device, vocab, epoch, validate_dataloader, log_step=100) -> Dict[str, float]:

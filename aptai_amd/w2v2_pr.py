@@ -101,21 +101,25 @@ class Wav2Vec2_PR(nn.Module):
         ops.cast_bf16(self.pr_head.weight.detach(), wp[:V])
         bp = torch.zeros(Np, device=h.device, dtype=torch.float32)
         bp[:V] = self.pr_head.bias.detach()
-        logits = ops.gemm(h, wp, g.M, Np, H, bias=bp, out_f32=True).view(g.B, g.Tp, Np)[:, :g.T, :V]
-        return out, logits
+        full = ops.gemm(h, wp, g.M, Np, H, bias=bp, out_f32=True)
+        out._logits_full = full                                   # [B*Tp][Np] fp32: what the device decode reads
+        return out, full.view(g.B, g.Tp, Np)[:, :g.T, :V]
 
-    def _decode(self, logits):
-        """Best-path decode of every utterance over ALL frames of the padded batch, like the reference's decoder call
-        (models/w2v2_pr.py:155 passes no lengths).  argmax runs on the device; ONE host transfer for the batch."""
-        blank = int(self.vocab.get('(blank)', 0)) if isinstance(self.vocab, dict) else 0
-        ids = logits.argmax(dim=-1).cpu().numpy()
-        out = []
-        for row in ids:
-            keep = np.ones(len(row), dtype=bool)
-            keep[1:] = row[1:] != row[:-1]
-            r = row[keep]
-            out.append(r[r != blank].astype(np.int64))
-        return out
+    def _blank(self) -> int:
+        return int(self.vocab.get('(blank)', 0)) if isinstance(self.vocab, dict) else 0
+
+    def _decode_device(self, out, max_n: int):
+        """Best-path decode on the device (aptai_ctc_greedy_decode): (ids int32 [B][max_n] zero-padded, n int32 [B]) over ALL
+        frames of the padded batch, like the reference's decoder call (models/w2v2_pr.py:155 passes no lengths).  Nothing
+        here synchronises host and device."""
+        g, full = out._geom, out._logits_full
+        return ops.ctc_greedy_decode(full, full.shape[1], g.Tp, g.B, g.T, self.pr_head.weight.shape[0], self._blank(), max_n)
+
+    def _decode(self, out):
+        """Decoded id lists of the batch: the device decode + ONE host transfer."""
+        ids, n = self._decode_device(out, out._geom.T)
+        ids, n = ids.cpu().numpy(), n.cpu().numpy()
+        return [ids[b, :n[b]].astype(np.int64) for b in range(len(n))]
 
     def get_embeddings(self, audio_inputs, audio_lengths):
         """models/w2v2_pr.py:124-167 (the encoder runs ONCE: the reference's extra feature_extractor pass :129 only
@@ -125,7 +129,7 @@ class Wav2Vec2_PR(nn.Module):
             out, logits = self._logits_eval(audio_inputs, audio_lengths[:, None] if audio_lengths.dim() == 1 else audio_lengths)
             frame_seq_lens = self.wav2vec2._get_feat_extract_output_lengths(audio_lengths)
             return {'features_hidden': None, 'last_transf_hidden': out.last_hidden_state.permute(0, 2, 1),
-                    'phoneme_logits': logits.cpu().numpy().transpose(0, 2, 1), 'phn_pred_seq_idx': self._decode(logits),
+                    'phoneme_logits': logits.cpu().numpy().transpose(0, 2, 1), 'phn_pred_seq_idx': self._decode(out),
                     'frame_seq_lens': frame_seq_lens.cpu().numpy(), '_out': out}
 
     def _wav(self, wav):
@@ -147,8 +151,8 @@ class Wav2Vec2_PR(nn.Module):
         self.eval()
         with torch.no_grad():
             _, wav_input, wav_len = self._wav(wav)
-            _, logits = self._logits_eval(wav_input, wav_len)
-            idx = self._decode(logits)[0]
+            out, logits = self._logits_eval(wav_input, wav_len)
+            idx = self._decode(out)[0]
             inv = {v: k for k, v in vocab.items()}
             return {'phn_seq_idx': idx, 'phn_seq_ipa': [inv.get(int(i), '?') for i in idx]}
 

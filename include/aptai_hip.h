@@ -229,18 +229,27 @@ int64_t aptai_aptai_loss_workspace_bytes(void);
  * of ForwardSumLoss (models/modules.py:99-116; vocab_sizes[b] = N_b + 1 classes, targets 1..N_b).
  * logits fp32 rows (b*rows_per_b + t) stride ldl; targets int32 [B][ldt] (any padding beyond target_lens[b]);
  * reduction 0 none / 1 mean (mean_b nll_b / max(len_b,1)) / 2 sum; nll fp32 [B]; loss fp32 scalar;
- * log_probs_out fp32 (T,B,V) or null; alpha_ws fp32 [B][T][2*ldt+1] kept for the backward. */
+ * log_probs_out fp32 (T,B,V) or null; workspace (aptai_ctc_workspace_bytes) holds alpha | beta | per-state log-probs and is
+ * handed unchanged to aptai_ctc_bwd.  want_beta != 0 runs the beta recursion beside the alpha recursion in the same launch
+ * (both are sequential over T and independent of each other): the backward is then one parallel pass. */
 int aptai_ctc_fwd(const float* logits, int64_t ldl, int64_t rows_per_b, const int32_t* targets, int64_t ldt,
                   const int32_t* input_lens, const int32_t* target_lens, const int32_t* vocab_sizes, int64_t B, int64_t T,
-                  int64_t V, int blank, int reduction, int zero_infinity, float* log_probs_out, float* alpha_ws, float* nll,
-                  float* loss, void* stream);
-/* dlogits rows (b*rows_per_b + t) stride ldd, bf16 or fp32, zero outside t < input_lens[b] and v < V;
- * gradient = grad_out[0] (device scalar, may be null = 1) * extra_scale * d loss / d logits. */
+                  int64_t V, int blank, int reduction, int zero_infinity, float* log_probs_out, float* workspace, float* nll,
+                  float* loss, int want_beta, void* stream);
+/* dlogits rows (b*rows_per_b + t) stride ldd (V <= ldd <= 256), bf16 or fp32, zero outside t < input_lens[b] and v < V;
+ * gradient = grad_out[0] (device scalar, may be null = 1) * extra_scale * d loss / d logits.  beta_ready = the forward call
+ * was made with want_beta (otherwise the beta recursion runs here first). */
 int aptai_ctc_bwd(const float* logits, int64_t ldl, int64_t rows_per_b, const int32_t* targets, int64_t ldt,
                   const int32_t* input_lens, const int32_t* target_lens, const int32_t* vocab_sizes, int64_t B, int64_t T,
-                  int64_t V, int blank, int reduction, int zero_infinity, const float* alpha_ws, const float* nll,
-                  const float* grad_out, float extra_scale, void* dlogits, int64_t ldd, int out_bf16, void* stream);
+                  int64_t V, int blank, int reduction, int zero_infinity, const float* workspace, const float* nll,
+                  const float* grad_out, float extra_scale, void* dlogits, int64_t ldd, int out_bf16, int beta_ready, void* stream);
 int64_t aptai_ctc_workspace_bytes(int64_t B, int64_t T, int64_t ldt);
+/* Best-path CTC decode on the device (stand-in for the torchaudio beam decoder the reference calls at models/w2v2_pr.py:143-159,
+ * which is absent here: parity unpinned): per utterance, frame argmax (first maximum) over ALL T rows, repeats collapsed, blank
+ * dropped.  ids_out int32 [B][max_n] zero-padded (the aligner's phoneme slots, models/force_aptai.py:109-115), n_out int32 [B] =
+ * decoded length, which the caller compares with max_n (models/force_aptai.py:111). */
+int aptai_ctc_greedy_decode(const float* logits, int64_t ldl, int64_t rows_per_b, int64_t B, int64_t T, int64_t V, int blank,
+                            int32_t* ids_out, int64_t max_n, int32_t* n_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ Force_APTAI heads (fp32)
  * Small layers behind the frozen encoder of models/force_aptai.py:108-161.  fp32 because they feed an argmax whose
@@ -248,9 +257,13 @@ int64_t aptai_ctc_workspace_bytes(int64_t B, int64_t T, int64_t ldt);
 /* C[m][n] (+)= alpha*sum_k A(m,k)*B(k,n) + bias[n];  A(m,k)=A[m*sam+k*sak] (fp32, or bf16 when a_bf16),
  * B(k,n)=B[k*sbk+n*sbn]; `batch` problems at element strides bsa/bsb/bsc.  Replaces nn.Linear (force_aptai.py:122,
  * modules.py:140-141,195-201) and torch.bmm (modules.py:144,149). */
+/* Runs on the f32-input matrix instruction (v_mfma_f32_32x32x2_f32): exact fp32 products and accumulation.  split_k > 1 cuts K
+ * into slabs (partials in `workspace`, aptai_sgemm_workspace_bytes, summed in slab order: deterministic) for gradient-shaped
+ * problems whose M x N alone cannot fill the chip. */
 int aptai_sgemm_f32(const void* A, int a_bf16, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
                     int64_t ldc, const float* bias, float alpha, int accumulate, int64_t M, int64_t N, int64_t K, int64_t batch,
-                    int64_t bsa, int64_t bsb, int64_t bsc, void* stream);
+                    int64_t bsa, int64_t bsb, int64_t bsc, int64_t split_k, float* workspace, void* stream);
+int64_t aptai_sgemm_workspace_bytes(int64_t M, int64_t N, int64_t batch, int64_t split_k);
 /* nn.Embedding(padding_idx=0) + PositionalEncoding (force_aptai.py:118-119, modules.py:217-235): out[r] = emb[ids[r]] + pe[r % N] */
 int aptai_embed_pe_fwd(const int32_t* ids, const float* emb, const float* pe, float* out, int64_t rows, int64_t N, int64_t D,
                        float dropout_p, uint64_t seed, void* stream);
@@ -258,28 +271,44 @@ int aptai_embed_bwd(const int32_t* ids, const float* dout, float* demb_zeroed, i
                     uint64_t seed, void* stream);
 /* CrossAttention softmax + the log-softmax alignment of force_aptai.py:128-130 and its argmax read-out (:148):
  * energy = raw + mask, att = softmax(energy), att_log = log_softmax(energy + mask), mask = -1000 where phn_ids == 0;
- * align int64 [B][T] = argmax_n att_log (first maximum), bit-exact integer output. */
+ * align int64 [B][T] = argmax_n att_log (first maximum), bit-exact integer output.  fs_rows (optional, [B*T][64]): the rows
+ * ForwardSumLoss feeds its CTC (models/modules.py:90-98) - blank log-prob -1 | att_log | zeros.  bwd: d_attlog rows have
+ * stride ld_dattlog (0 = N), so the CTC gradient of those 64-float rows is read in place (pointer + 1). */
 int aptai_xattn_softmax_fwd(const float* raw, const int32_t* phn_ids, float* energy, float* att, float* att_log, int64_t* align,
-                            int64_t B, int64_t T, int64_t N, void* stream);
-int aptai_xattn_softmax_bwd(const float* att, const float* att_log, const float* d_att, const float* d_attlog, float* d_raw,
-                            int64_t rows, int64_t N, void* stream);
+                            float* fs_rows, int64_t B, int64_t T, int64_t N, void* stream);
+int aptai_xattn_softmax_bwd(const float* att, const float* att_log, const float* d_att, const float* d_attlog, int64_t ld_dattlog,
+                            float* d_raw, int64_t rows, int64_t N, void* stream);
 int aptai_layernorm_f32_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows,
                             int64_t cols, float eps, void* stream);
 int aptai_layernorm_f32_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
                             float* dgamma_zeroed, float* dbeta_zeroed, int64_t rows, int64_t cols, void* stream);
 /* nn.LSTM(256,256,bidirectional) over packed sequences (modules.py:195,204-206): xproj [B*Tp][2][1024] = x W_ih^T + b_ih + b_hh,
- * whhT [2][256][1024] (transposed weight_hh), lens int32 [B]; hout [B*Tp][512] (zeros beyond lens); gates/cstate saved for bwd. */
-int aptai_lstm_fwd(const float* xproj, const float* whhT, const int32_t* lens, float* hout, float* gates, float* cstate, int64_t B,
-                   int64_t Tp, int64_t T, int64_t hidden, void* stream);
+ * whh [2][1024][256] (weight_hh_l0, weight_hh_l0_reverse as stored), lens int32 [B]; hout [B*Tp][512] (zeros beyond lens);
+ * gates (post-activation i,f,g,o) [B*Tp][2][1024] and cstate [B*Tp][2][256] are saved for the backward (both null in
+ * inference).  16 cooperating workgroups per (16 utterances, direction) keep W_hh in registers and exchange h through
+ * `workspace` (aptai_lstm_workspace_bytes; zero-initialised ONCE by the caller, its first 256 bytes are a status word that
+ * turns non-zero if a bounded wait ever timed out).  bwd: dgates [B*Tp][2][1024] = gradients w.r.t. the gate pre-activations
+ * (zeros beyond lens). */
+int aptai_lstm_fwd(const float* xproj, const float* whh, const int32_t* lens, float* hout, float* gates, float* cstate,
+                   void* workspace, int64_t B, int64_t Tp, int64_t T, int64_t hidden, void* stream);
 int aptai_lstm_bwd(const float* dhout, const float* whh, const int32_t* lens, const float* gates, const float* cstate, float* dgates,
-                   int64_t B, int64_t Tp, int64_t T, int64_t hidden, void* stream);
+                   void* workspace, int64_t B, int64_t Tp, int64_t T, int64_t hidden, void* stream);
+int64_t aptai_lstm_workspace_bytes(int64_t B);
+/* the same recurrences, one block per (utterance, direction), W_hh streamed from L2 on every frame (whhT [2][256][1024] for the
+ * forward): the on-device cross-check of the kernels above, not on the hot path */
+int aptai_lstm_fwd_serial(const float* xproj, const float* whhT, const int32_t* lens, float* hout, float* gates, float* cstate,
+                          int64_t B, int64_t Tp, int64_t T, int64_t hidden, void* stream);
+int aptai_lstm_bwd_serial(const float* dhout, const float* whh, const int32_t* lens, const float* gates, const float* cstate,
+                          float* dgates, int64_t B, int64_t Tp, int64_t T, int64_t hidden, void* stream);
 /* pred_frame_phns (force_aptai.py:152-161): out[b][t] = phn_table[b][align[b][t]] for t < lens[b], else -1 (int64) */
 int aptai_gather_alignment(const int32_t* phn_table, const int64_t* align, const int32_t* lens, int64_t* out, int64_t B, int64_t T,
                            int64_t N, void* stream);
 int aptai_tanh_dropout_f32(const float* x, const float* y_or_null, const float* dy_or_null, float* out, int64_t n, float dropout_p,
                            uint64_t seed, void* stream);
 int aptai_dropout_f32(const float* x, float* y, int64_t n, float dropout_p, uint64_t seed, void* stream);
-int aptai_colsum_f32(const float* x, int64_t ld, float* out, int64_t rows, int64_t N, void* stream);
+/* out[n] = sum_r x[r*ld + n] (bias gradients of the fp32 heads), two deterministic stages through `workspace` */
+int aptai_colsum_f32(const float* x, int64_t ld, float* out, float* workspace, int64_t rows, int64_t N, void* stream);
+int64_t aptai_colsum_f32_workspace_bytes(int64_t N);
 
 #ifdef __cplusplus
 }

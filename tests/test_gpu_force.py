@@ -16,15 +16,71 @@ pytestmark = pytest.mark.gpu
 TV = ("LA", "LP", "JA", "TTCL", "TTCD", "TMCL", "TMCD", "TBCL", "TBCD")
 
 
-def test_lstm_kernels_match_torch_packed_lstm():
+def _sgemm_ref(a, b):
+    return (a.double() @ b.double()).float()
+
+
+def test_sgemm_f32_on_the_matrix_cores_matches_fp64():
+    """aptai_sgemm_f32 (v_mfma_f32_32x32x2_f32): every operand orientation, the bf16 A operand, batches, ragged edges, bias /
+    alpha / accumulate and the split-K form, against an fp64 product (fp32 rounding only: 1e-6 relative)."""
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(3)
+
+    def close(got, ref, tol=2e-6):
+        err = (got.cpu().double() - ref.double()).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()) * (ref.shape[-1] ** 0 ) + tol, (err, ref.abs().max().item())
+
+    # A row-major [M][K], B as nn.Linear weight [N][K]  (x W^T + b)
+    for (M, N, K) in ((300, 128, 768), (64, 9, 256), (1000, 60, 128), (256, 2048, 256)):
+        a, w, bias = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+        got = ops.linear_f32(a.cuda(), w.cuda(), bias.cuda())
+        close(got, _sgemm_ref(a, w.t()) + bias, 3e-6)
+    # bf16 A (encoder output), strided rows
+    a = torch.randn(512, 800, generator=g).to(torch.bfloat16)
+    w = torch.randn(128, 768, generator=g) / 28
+    got = ops.linear_f32(a.cuda()[:, :768], w.cuda(), None, rows=512, ldx=800)
+    close(got, _sgemm_ref(a[:, :768].float(), w.t()), 3e-6)
+    # A^T B with a long K (gradient shape): split-K and single pass agree with fp64
+    M, N, K = 256, 512, 8192
+    a, b = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    ref = _sgemm_ref(a.t(), b)
+    for sk in (1, None, 7):
+        got = ops.sgemm(a.cuda(), 1, M, b.cuda(), N, 1, M, N, K, split_k=sk)
+        assert ((got.cpu().double() - ref.double()).norm() / ref.double().norm()).item() < 2e-6, sk
+    # batched, alpha, accumulate into a strided C
+    Bn, M, N, K = 3, 100, 60, 128
+    a, b = torch.randn(Bn, M, K, generator=g), torch.randn(Bn, N, K, generator=g)
+    c0 = torch.randn(Bn, M, 64, generator=g)
+    c = c0.clone().cuda()
+    ops.sgemm(a.cuda(), K, 1, b.cuda(), 1, K, M, N, K, out=c, ldc=64, alpha=0.5, accumulate=True, batch=Bn, bsa=M * K, bsb=N * K,
+              bsc=M * 64)
+    ref = c0.clone()
+    ref[:, :, :N] += 0.5 * torch.einsum("bmk,bnk->bmn", a.double(), b.double()).float()
+    close(c, ref, 3e-6)
+    assert torch.equal(c.cpu()[:, :, N:], c0[:, :, N:])                       # columns beyond N untouched
+
+
+def test_colsum_f32_two_stage():
+    from aptai_amd import ops
+    x = torch.randn(8192, 300, generator=torch.Generator().manual_seed(1))
+    got = ops.colsum_f32(x.cuda()[:, :290], 8192, 290, ld=300).cpu()
+    ref = x[:, :290].double().sum(0)
+    assert (got.double() - ref).abs().max().item() < 2e-5 * 90
+
+
+@pytest.mark.parametrize("B,lens", [(3, [50, 37, 5]), (16, [50, 50, 49, 48, 40, 33, 32, 31, 17, 16, 15, 9, 3, 2, 1, 50]),
+                                    (20, [50] * 4 + [44, 30, 12] * 5 + [1])])
+def test_lstm_kernels_match_torch_packed_lstm(B, lens):
+    """Cooperating-workgroup BiLSTM (csrc/lstm.hip) against torch.nn.LSTM over packed sequences, forward and backward, incl. a batch
+    that spans two 16-utterance groups, and against the serial one-block-per-utterance kernels."""
     from aptai_amd import ops
     from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
     torch.manual_seed(0)
-    B, T, Tp = 3, 50, 128
-    lens = [50, 37, 5]
+    T, Tp = 50, 128
     lstm = torch.nn.LSTM(256, 256, bidirectional=True, num_layers=1, batch_first=True)
     x = torch.randn(B, T, 256, requires_grad=True)
-    out, _ = pad_packed_sequence(lstm(pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False))[0], batch_first=True)
+    out, _ = pad_packed_sequence(lstm(pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False))[0], batch_first=True,
+                                 total_length=T)
     gout = torch.randn_like(out)
     for b, L in enumerate(lens):
         gout[b, L:] = 0
@@ -34,16 +90,25 @@ def test_lstm_kernels_match_torch_packed_lstm():
     wih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]).detach()
     bsum = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach()
     xproj = ops.linear_f32(xp.view(B * Tp, 256).cuda(), wih.cuda(), bsum.cuda())
-    whh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]).detach()
-    whhT = whh.transpose(1, 2).contiguous()
+    whh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]).detach().contiguous()
     lens_t = torch.tensor(lens, dtype=torch.int32).cuda()
-    hout, gates, cst = ops.lstm_fwd(xproj, whhT.cuda(), lens_t, B, Tp, T)
+    hout, gates, cst = ops.lstm_fwd(xproj, whh.cuda(), lens_t, B, Tp, T)
+    torch.cuda.synchronize()
+    assert ops.lstm_status("cuda:0") == 0
     got = hout.view(B, Tp, 512)[:, :T].cpu()
     assert (got - out.detach()).abs().max().item() < 2e-5
-    assert hout.view(B, Tp, 512)[1, 37:].abs().max().item() == 0.0
+    for b, L in enumerate(lens):
+        assert hout.view(B, Tp, 512)[b, L:].abs().max().item() == 0.0
+    # the serial kernels see the same inputs: same recurrence, different summation order
+    h2, g2, c2 = ops.lstm_fwd_serial(xproj, whh.transpose(1, 2).contiguous().cuda(), lens_t, B, Tp, T)
+    assert (h2 - hout).abs().max().item() < 1e-5
     dh = torch.zeros(B, Tp, 512)
     dh[:, :T] = gout
     dgates = ops.lstm_bwd(dh.view(B * Tp, 512).cuda(), whh.cuda(), lens_t, gates, cst, B, Tp, T)
+    torch.cuda.synchronize()
+    assert ops.lstm_status("cuda:0") == 0
+    dg2 = ops.lstm_bwd_serial(dh.view(B * Tp, 512).cuda(), whh.cuda(), lens_t, g2, c2, B, Tp, T)
+    assert (dg2 - dgates).abs().max().item() < 2e-5 * max(1.0, dg2.abs().max().item())
     dx = ops.sgemm(dgates, 2048, 1, wih.cuda(), 256, 1, B * Tp, 256, 2048).view(B, Tp, 256)[:, :T].cpu()
     assert (dx - x.grad).abs().max().item() < 5e-5 * max(1.0, x.grad.abs().max().item())
     dwih = ops.sgemm(dgates, 1, 2048, xp.view(B * Tp, 256).cuda(), 256, 1, 2048, 256, B * Tp).cpu()

@@ -267,8 +267,8 @@ def test_force_alignment_indices_exact_outside_the_measured_noise():
     batch = synth.synth_aptai_batch(pr_cfg, 2, 24000, seed=5, n_phn=40)
     with torch.no_grad():
         ref = heads_ref.force_aptai_forward(sd, pr_cfg, batch["audio_inputs"], batch["audio_lengths"], [batch[n] for n in TV])
-        res, g, lists, frame_lens, phn_lens, ids = model._run(batch["audio_inputs"].cuda(), batch["audio_lengths"].cuda(),
-                                                              phn_pred_list=ref["pred_ctc_phn_seq"])
+        res, g, dec = model._run(batch["audio_inputs"].cuda(), batch["audio_lengths"].cuda(), phn_pred_list=ref["pred_ctc_phn_seq"])
+        lists, frame_lens, phn_lens, _ = model._lists(dec)
     att_gpu = res[5].view(g.B, g.Tp, 60)[:, :g.T].float().cpu().numpy()
     att_ref = ref["att"].numpy()
     align_gpu = res[8].view(g.B, g.Tp)[:, :g.T].cpu().numpy()
@@ -308,9 +308,16 @@ def test_force_inference_helpers_against_the_oracle():
     a = torch.from_numpy(wav)[None]
     T = len(z["b1/pred_frame_phns"])
     with torch.no_grad():
-        e = heads_ref.pr_get_embeddings(sd, pr_cfg, a, torch.tensor([len(wav)]), prefix="w2v2_pr.")
-        lst = [heads_ref.ctc_best_path(e["phoneme_logits"][0].numpy())]
-        assert len(lst[0]) >= 2 and e["phoneme_logits"].shape[1] == T
+        # lower the blank bias of the synthetic recogniser until this clip decodes to a usable phoneme list (2..40 ids)
+        for _ in range(12):
+            e = heads_ref.pr_get_embeddings(sd, pr_cfg, a, torch.tensor([len(wav)]), prefix="w2v2_pr.")
+            lst = [heads_ref.ctc_best_path(e["phoneme_logits"][0].numpy())]
+            if 2 <= len(lst[0]) <= 40:
+                break
+            step = -0.25 if len(lst[0]) < 2 else 0.25
+            sd["w2v2_pr.pr_head.bias"][0] += step
+            model.w2v2_pr.pr_head.bias.data[0] += step
+        assert 2 <= len(lst[0]) <= 40 and e["phoneme_logits"].shape[1] == T
         dummy = [torch.full((1, T), -100.0, dtype=torch.float64)] * 9
         ref = heads_ref.force_aptai_forward(sd, pr_cfg, a, torch.tensor([len(wav)]), dummy, phn_pred_list=lst)
     al = model.get_alignment(wav)["alignment"]
@@ -334,3 +341,74 @@ def test_force_inference_helpers_against_the_oracle():
     assert out["hidden_alignment"].shape == (1, T, 256) and out["hidden_tvs"].shape == (1, T, 512)
     ha = ref["att_out"].numpy()
     assert np.linalg.norm(out["hidden_alignment"].cpu().numpy() - ha) < 5e-2 * np.linalg.norm(ha)
+
+
+# ------------------------------------------------------------------------------------------------ stand-alone head blocks
+def test_module_forwards_stand_alone_against_the_oracle():
+    """CrossAttention / RNN / PositionalEncoding / ForwardSumLoss used on their OWN (models/modules.py:77-117,139-153,203-214,
+    229-235): forward values and gradients against the oracle's restatement of the same blocks (fp32 both sides)."""
+    from aptai_amd import modules as M
+    from oracle import heads_ref, synth
+    from aptai_amd.config import W2V2Config
+    z, meta = load_golden("force_aptai_1x2s")
+    pr_cfg = W2V2Config.from_any(meta["pr_cfg"])
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, meta["vocab_len"]), meta["seed"])
+    g = torch.Generator().manual_seed(4)
+
+    def rel(a, b):
+        return ((a.detach().cpu().double() - b.detach().double()).norm() / (b.detach().double().norm() + 1e-30)).item()
+
+    # ---- CrossAttention on the reference fixture's own inputs (b2/*)
+    xatt = M.CrossAttention(128, 128, 128).cuda()
+    xatt.load_state_dict({k[len("xatt."):]: v for k, v in sd.items() if k.startswith("xatt.")})
+    frame, phn = torch.from_numpy(z["b2/frame"]), torch.from_numpy(z["b2/phn_embs"])
+    mask = (torch.from_numpy(z["b2/phn_ids"]) != 0).to(torch.int)
+    fr_g, ph_g = frame.cuda().requires_grad_(True), phn.cuda().requires_grad_(True)
+    att_out, energy = xatt(fr_g, ph_g, mask.cuda())
+    assert np.allclose(att_out.detach().cpu().numpy(), z["b2/att_out"], atol=2e-4)
+    assert np.allclose(energy.detach().cpu().numpy(), z["b2/energy"], rtol=1e-5, atol=2e-4)
+    wgt = torch.randn(att_out.shape, generator=g)
+    (att_out * wgt.cuda()).sum().backward()
+    sdo = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in sd.items() if k.startswith("xatt.")}
+    fr_o, ph_o = frame.clone().requires_grad_(True), phn.clone().requires_grad_(True)
+    ao, _ = heads_ref.cross_attention(sdo, fr_o, ph_o, mask)
+    (ao * wgt).sum().backward()
+    assert rel(fr_g.grad, fr_o.grad) < 2e-3 and rel(ph_g.grad, ph_o.grad) < 2e-3
+    for n, p in xatt.named_parameters():
+        assert rel(p.grad, sdo["xatt." + n].grad) < 2e-3, n
+    # ---- RNN (batch 2, packed) on the fixture's att_out
+    rnn = M.RNN(256, 9, 0.1).cuda().eval()
+    rnn.load_state_dict({k[len("rnn."):]: v for k, v in sd.items() if k.startswith("rnn.")})
+    lens = [int(v) for v in z["b2/mel_lens"]]
+    x_g = torch.from_numpy(z["b2/att_out"]).cuda().requires_grad_(True)
+    out, hid = rnn(x_g, lens)
+    Tm = max(lens)
+    assert np.abs(out.detach().cpu().numpy() - z["b2/rnn_out"][:, :Tm]).max() < 2e-4
+    assert np.abs(hid.detach().cpu().numpy() - z["b2/lstm_out"][:, :Tm]).max() < 2e-4
+    wr = torch.randn(out.shape, generator=g)
+    (out * wr.cuda()).sum().backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("rnn.")}
+    x_o = torch.from_numpy(z["b2/att_out"]).clone().requires_grad_(True)
+    oo, _ = heads_ref.rnn_forward(sdr, x_o, lens)
+    (oo * wr).sum().backward()
+    assert rel(x_g.grad, x_o.grad) < 2e-3
+    for n, p in rnn.named_parameters():
+        assert rel(p.grad, sdr["rnn." + n].grad) < 3e-3, n
+    # ---- PositionalEncoding (eval: no dropout) and ForwardSumLoss
+    pe = M.PositionalEncoding(128, dropout=0.2, max_len=60).cuda().eval()
+    xs = torch.randn(60, 2, 128, generator=g)
+    assert torch.allclose(pe(xs.cuda()).cpu(), xs + heads_ref.positional_encoding(128, 60), atol=1e-6)
+    pe.train()
+    yd = pe(xs.cuda()).cpu()
+    kept = yd != 0
+    assert 0.7 < kept.float().mean().item() < 0.9                       # p = 0.2
+    assert torch.allclose(yd[kept], ((xs + heads_ref.positional_encoding(128, 60)) / 0.8)[kept], rtol=1e-3, atol=1e-5)
+    fsl = M.ForwardSumLoss()
+    att = torch.from_numpy(z["b2/att"])
+    a_g = att.cuda().unsqueeze(1).requires_grad_(True)
+    loss = fsl(a_g, z["b2/text_lens"], z["b2/mel_lens"])
+    assert abs(loss.item() - float(z["b2/fs_loss"])) < 2e-4 * abs(float(z["b2/fs_loss"]))
+    loss.backward()
+    a_o = att.clone().unsqueeze(1).requires_grad_(True)
+    heads_ref.forward_sum_loss(a_o, [int(v) for v in z["b2/text_lens"]], [int(v) for v in z["b2/mel_lens"]]).backward()
+    assert rel(a_g.grad, a_o.grad) < 2e-3
