@@ -66,7 +66,8 @@ ARGTYPES = {
     "aptai_xattn_softmax_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "aptai_xattn_softmax_bwd": [_P, _P, _P, _P, _I64, _P, _I64, _I64, _P],
     "aptai_layernorm_f32_fwd": [_P, _P, _P, _P, _P, _P, _I64, _I64, _F, _P],
-    "aptai_layernorm_f32_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P],
+    "aptai_layernorm_f32_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P],
+    "aptai_layernorm_f32_bwd_workspace_bytes": [_I64],
     "aptai_lstm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "aptai_lstm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "aptai_lstm_workspace_bytes": [_I64],

@@ -39,34 +39,33 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
     const float* Bp = g.B + (long)bz * g.bsb;
     f32x16 acc = (f32x16)(0.f);
     const bool m_full = m0 + 64 <= g.M, n_full = n0 + 64 <= g.N;
-    for (long k0 = kbeg; k0 < kend; k0 += SG_BK) {
+    // staging goes through registers: the loads of K-tile t+1 are issued before the MFMAs of tile t and land under them
+    // (8 values per thread and operand).  pa / pb = how this tile was fetched: 0 scalar guarded, 1 16-byte loads along k,
+    // 2 16-byte loads along m / n, 3 (A only) 8 bf16 along k.
+    float ra[8], rb[8];
+    int pa = 0, pb = 0;
+    auto fetch = [&](long k0) {
         const bool k_full = k0 + SG_BK <= kend;
-        // ---- A tile: 64 (m) x 32 (k) -> As[k][m]
-        if (g.vec_a && m_full && k_full && g.sak == 1) {
-            if (g.a_bf16) {                                   // 8 bf16 per thread
-                const int row = tid >> 2, k8 = (tid & 3) * 8;
-                const u32x4 v = *(const u32x4*)(Ab + (long)(m0 + row) * g.sam + k0 + k8);
+        pa = 0;
+        if (g.vec_a && m_full && k_full) pa = g.sak == 1 ? (g.a_bf16 ? 3 : 1) : ((g.sam == 1 && !g.a_bf16) ? 2 : 0);
+        if (pa == 3) {
+            const int row = tid >> 2, k8 = (tid & 3) * 8;
+            const u32x4 v = *(const u32x4*)(Ab + (long)(m0 + row) * g.sam + k0 + k8);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    As[(k8 + 2 * j) * SG_P + row] = lo_bf(v[j]);
-                    As[(k8 + 2 * j + 1) * SG_P + row] = hi_bf(v[j]);
-                }
-            } else {
+            for (int j = 0; j < 4; ++j) { ra[2 * j] = lo_bf(v[j]); ra[2 * j + 1] = hi_bf(v[j]); }
+        } else if (pa == 1) {
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int idx = e * 256 + tid, row = idx >> 3, k4 = (idx & 7) * 4;
-                    const sg_f4 v = *(const sg_f4*)(Af + (long)(m0 + row) * g.sam + k0 + k4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) As[(k4 + j) * SG_P + row] = v[j];
-                }
+            for (int e = 0; e < 2; ++e) {
+                const int idx = e * 256 + tid, row = idx >> 3, k4 = (idx & 7) * 4;
+                const sg_f4 v = *(const sg_f4*)(Af + (long)(m0 + row) * g.sam + k0 + k4);
+                ra[4 * e] = v[0]; ra[4 * e + 1] = v[1]; ra[4 * e + 2] = v[2]; ra[4 * e + 3] = v[3];
             }
-        } else if (g.vec_a && m_full && k_full && g.sam == 1 && !g.a_bf16) {
+        } else if (pa == 2) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int idx = e * 256 + tid, kk = idx >> 4, m4 = (idx & 15) * 4;
                 const sg_f4 v = *(const sg_f4*)(Af + (k0 + kk) * g.sak + m0 + m4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) As[kk * SG_P + m4 + j] = v[j];
+                ra[4 * e] = v[0]; ra[4 * e + 1] = v[1]; ra[4 * e + 2] = v[2]; ra[4 * e + 3] = v[3];
             }
         } else {
 #pragma unroll
@@ -81,25 +80,24 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
                     const long off = (long)m * g.sam + k * g.sak;
                     v = g.a_bf16 ? bf2f(Ab[off]) : Af[off];
                 }
-                As[kk * SG_P + mm] = v;
+                ra[e] = v;
             }
         }
-        // ---- B tile: 32 (k) x 64 (n) -> Bs[k][n]
-        if (g.vec_b && n_full && k_full && g.sbn == 1) {
+        pb = 0;
+        if (g.vec_b && n_full && k_full) pb = g.sbn == 1 ? 2 : (g.sbk == 1 ? 1 : 0);
+        if (pb == 2) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int idx = e * 256 + tid, kk = idx >> 4, n4 = (idx & 15) * 4;
                 const sg_f4 v = *(const sg_f4*)(Bp + (k0 + kk) * g.sbk + n0 + n4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[kk * SG_P + n4 + j] = v[j];
+                rb[4 * e] = v[0]; rb[4 * e + 1] = v[1]; rb[4 * e + 2] = v[2]; rb[4 * e + 3] = v[3];
             }
-        } else if (g.vec_b && n_full && k_full && g.sbk == 1) {
+        } else if (pb == 1) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int idx = e * 256 + tid, col = idx >> 3, k4 = (idx & 7) * 4;
                 const sg_f4 v = *(const sg_f4*)(Bp + (long)(n0 + col) * g.sbn + k0 + k4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[(k4 + j) * SG_P + col] = v[j];
+                rb[4 * e] = v[0]; rb[4 * e + 1] = v[1]; rb[4 * e + 2] = v[2]; rb[4 * e + 3] = v[3];
             }
         } else {
 #pragma unroll
@@ -111,10 +109,67 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
                 const long k = k0 + kk;
                 float v = 0.f;
                 if (n < g.N && k < kend) v = Bp[k * g.sbk + (long)n * g.sbn];
-                Bs[kk * SG_P + nn] = v;
+                rb[e] = v;
             }
         }
+    };
+    auto stage = [&]() {                                        // registers -> As[k][m], Bs[k][n]
+        if (pa == 3) {
+            const int row = tid >> 2, k8 = (tid & 3) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) As[(k8 + j) * SG_P + row] = ra[j];
+        } else if (pa == 1) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = e * 256 + tid, row = idx >> 3, k4 = (idx & 7) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[(k4 + j) * SG_P + row] = ra[4 * e + j];
+            }
+        } else if (pa == 2) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = e * 256 + tid, kk = idx >> 4, m4 = (idx & 15) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[kk * SG_P + m4 + j] = ra[4 * e + j];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = e * 256 + tid;
+                int mm, kk;
+                if (g.sak == 1) { kk = idx & 31; mm = idx >> 5; } else { mm = idx & 63; kk = idx >> 6; }
+                As[kk * SG_P + mm] = ra[e];
+            }
+        }
+        if (pb == 2) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = e * 256 + tid, kk = idx >> 4, n4 = (idx & 15) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[kk * SG_P + n4 + j] = rb[4 * e + j];
+            }
+        } else if (pb == 1) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = e * 256 + tid, col = idx >> 3, k4 = (idx & 7) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[(k4 + j) * SG_P + col] = rb[4 * e + j];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = e * 256 + tid;
+                int nn, kk;
+                if (g.sbn == 1) { nn = idx & 63; kk = idx >> 6; } else { kk = idx & 31; nn = idx >> 5; }
+                Bs[kk * SG_P + nn] = rb[e];
+            }
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (long k0 = kbeg; k0 < kend; k0 += SG_BK) {
+        stage();
         __syncthreads();
+        if (k0 + SG_BK < kend) fetch(k0 + SG_BK);
         const float* ap = As + (lane >> 5) * SG_P + wm * 32 + (lane & 31);
         const float* bp = Bs + (lane >> 5) * SG_P + wn * 32 + (lane & 31);
 #pragma unroll
@@ -253,30 +308,63 @@ __global__ __launch_bounds__(256) void ln32_fwd_kernel(const float* __restrict__
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
+// dgamma / dbeta: per-lane register partials over the rows a wave walks, one [2][cols] slab per block (no atomics: the 2 M
+// atomicAdds of the first version took 343 us), summed in block order by ln32_bwd_final_kernel
+constexpr int LN32_BLOCKS = 256;
 __global__ __launch_bounds__(256) void ln32_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta, long rows, int cols) {
-    const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
+                                                       const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ ws,
+                                                       long rows, int cols) {
+    __shared__ float red[4][2][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per = cols / 64;
-    const float mu = mean[row], rs = rstd[row];
-    float xh[16], gd[16];
-    float s1 = 0.f, s2 = 0.f;
-    for (int j = 0; j < per; ++j) {
-        const int c = j * 64 + lane;
-        const float d = dy[row * cols + c];
-        xh[j] = (x[row * cols + c] - mu) * rs;
-        gd[j] = d * gamma[c];
-        s1 += gd[j];
-        s2 += gd[j] * xh[j];
-        atomicAdd(&dgamma[c], d * xh[j]);
-        atomicAdd(&dbeta[c], d);
+    float ag[16], ab[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[16], gd[16];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j >= per) break;
+            const int c = j * 64 + lane;
+            const float d = dy[row * cols + c];
+            xh[j] = (x[row * cols + c] - mu) * rs;
+            gd[j] = d * gamma[c];
+            s1 += gd[j];
+            s2 += gd[j] * xh[j];
+            ag[j] += d * xh[j];
+            ab[j] += d;
+        }
+        s1 = wave_sum(s1) / cols;
+        s2 = wave_sum(s2) / cols;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j >= per) break;
+            dx[row * cols + j * 64 + lane] = rs * (gd[j] - s1 - xh[j] * s2);
+        }
     }
-    s1 = wave_sum(s1) / cols;
-    s2 = wave_sum(s2) / cols;
-    for (int j = 0; j < per; ++j) dx[row * cols + j * 64 + lane] = rs * (gd[j] - s1 - xh[j] * s2);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j >= per) break;
+        red[wave][0][j * 64 + lane] = ag[j];
+        red[wave][1][j * 64 + lane] = ab[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * cols; i += 256) {
+        const int which = i / cols, c = i % cols;
+        ws[((long)blockIdx.x * 2 + which) * cols + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+__global__ void ln32_bwd_final_kernel(const float* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta, int blocks,
+                                      int cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * cols) return;
+    const int which = i / cols, c = i % cols;
+    float s = 0.f;
+    for (int b = 0; b < blocks; ++b) s += ws[((long)b * 2 + which) * cols + c];
+    (which ? dbeta : dgamma)[c] = s;
 }
 
 // ------------------------------------------------------------------------------------------ BiLSTM (hidden 256), serial form
@@ -518,13 +606,20 @@ extern "C" int aptai_layernorm_f32_fwd(const float* x, const float* gamma, const
     APTAI_CHECK_LAUNCH("ln32_fwd_kernel");
     return APTAI_OK;
 }
+extern "C" int64_t aptai_layernorm_f32_bwd_workspace_bytes(int64_t cols) { return (int64_t)LN32_BLOCKS * 2 * cols * 4; }
 extern "C" int aptai_layernorm_f32_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                       float* dx, float* dgamma_zeroed, float* dbeta_zeroed, int64_t rows, int64_t cols, void* stream) {
-    APTAI_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma_zeroed && dbeta_zeroed && cols % 64 == 0 && cols <= 1024,
+                                       float* dx, float* dgamma, float* dbeta, float* workspace, int64_t rows, int64_t cols,
+                                       void* stream) {
+    APTAI_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && cols % 64 == 0 && cols <= 1024,
                   "aptai_layernorm_f32_bwd: bad arguments");
-    APTAI_LAUNCH(ln32_bwd_kernel, dim3((unsigned)ceil_div(rows * 64, 256)), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma,
-                 dx, dgamma_zeroed, dbeta_zeroed, (long)rows, (int)cols);
+    long blocks = ceil_div(rows, 4);
+    if (blocks > LN32_BLOCKS) blocks = LN32_BLOCKS;
+    APTAI_LAUNCH(ln32_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dx, workspace,
+                 (long)rows, (int)cols);
     APTAI_CHECK_LAUNCH("ln32_bwd_kernel");
+    APTAI_LAUNCH(ln32_bwd_final_kernel, dim3((unsigned)ceil_div(2 * cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                 (const float*)workspace, dgamma, dbeta, (int)blocks, (int)cols);
+    APTAI_CHECK_LAUNCH("ln32_bwd_final_kernel");
     return APTAI_OK;
 }
 

@@ -31,13 +31,14 @@ constexpr unsigned LC_SPIN_LIMIT = 1u << 22;
 
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((ext_vector_type(2))) u64 u64x2;
 
 struct LstmArgs {
     const float* xproj; const float* whh; const int* lens;
     float* hout; float* gates; float* cstate;
     const float* dhout; const float* gates_in; const float* cstate_in; float* dgates;
     u64* ex; unsigned* status;
-    int B, Tp, T, bgroup0;
+    int B, Tp, T, bgroup0, nclusters;
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -71,13 +72,24 @@ __device__ __forceinline__ bool sweep(const gu64* src, long stride, unsigned tag
     }
 }
 
+// Placement (speed only, never correctness): workgroups b and b + 8 share an XCD under the observed round-robin dispatch, so
+// a cluster takes the 16 workgroups {8 i + x : i = 0..15} of one XCD label x and exchanges through ONE L2; the launch spans
+// 8 x 16 x ceil(clusters / 8) workgroups and the labels without a cluster exit at once.
+__device__ __forceinline__ bool cluster_of_block(int nclusters, int& cluster, int& k) {
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    cluster = x + 8 * (i >> 4);
+    k = i & 15;
+    return cluster < nclusters;
+}
+
 // ================================================================================================ forward
 // grid = clusters x 16, 256 threads.  wave w, lane (j = lane & 15, q = lane >> 4): gate column j of the wave's n-tile =
 // (unit 16k + 4w + (j >> 2), gate j & 3); MFMA k index (q, ss) <-> hidden unit q*64 + ss; C rows = utterances 4q + reg.
 __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float hs[16 * LH];       // h_{t-1} as MFMA A image: [c 0..15][lane][4 floats]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cluster = blockIdx.x / LC_WG, k = blockIdx.x % LC_WG;
+    int cluster, k;
+    if (!cluster_of_block(a.nclusters, cluster, k)) return;
     const int dir = cluster & 1, bg = a.bgroup0 + (cluster >> 1);
     const int j = lane & 15, q = lane >> 4;
     const int unit = k * 16 + wave * 4 + (j >> 2), gate = j & 3;
@@ -130,14 +142,17 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
                 hs[c * 256 + (qq * 16 + i) * 4 + e] = __uint_as_float((unsigned)g[r]);
             }
             __syncthreads();
+            // two accumulator chains: a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one issues after 32
+            f32x4 acc2 = (f32x4)(0.f);
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const f32x4 av = *(const f32x4*)&hs[c * 256 + lane * 4];
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], w[4 * c], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], w[4 * c + 1], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], w[4 * c + 1], acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], w[4 * c + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], w[4 * c + 3], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], w[4 * c + 3], acc2, 0, 0, 0);
             }
+            acc += acc2;
             __syncthreads();                                            // the image is free for the next frame's gather
         }
         // ---- the four gates of (utterance 4q + slot, unit) sit in the four lanes of the quad, register = slot: 4 x 4 transpose
@@ -170,6 +185,19 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
     }
 }
 
+// 16-byte write-through store / L1-bypassing load of TWO adjacent granules (guide, Guideline 16 R1: sc1 stores, sc1 loads; a
+// 16-byte sc1 access was observed untorn per 8-byte half on gfx950, and every granule carries its own tag, so a torn pair
+// would only make the sweep retry).  aux = 16 selects sc1 on the raw buffer instructions.
+__device__ __forceinline__ void store_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, u64 g0, u64 g1) {
+    const u32x4 v = {(uint32_t)g0, (uint32_t)(g0 >> 32), (uint32_t)g1, (uint32_t)(g1 >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, byte_off, 0, 16);
+}
+__device__ __forceinline__ void load_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, u64& g0, u64& g1) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);
+    g0 = ((u64)v[1] << 32) | v[0];
+    g1 = ((u64)v[3] << 32) | v[2];
+}
+
 // ================================================================================================ backward through time
 // thread (eb = tid & 15, eu = tid >> 4) owns (utterance eb, unit 16k + eu) of the elementwise part; MFMA: A = the workgroup's
 // pre-activation gradients [16 utterances][64 gate columns] (k index (q, ss) <-> gate q, unit 16k + ss), B = W_hh rows of those
@@ -177,7 +205,8 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
 __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float dgs[16 * 64];      // A image: [c 0..3][lane][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cluster = blockIdx.x / LC_WG, k = blockIdx.x % LC_WG;
+    int cluster, k;
+    if (!cluster_of_block(a.nclusters, cluster, k)) return;
     const int dir = cluster & 1, bg = a.bgroup0 + (cluster >> 1);
     const int j = lane & 15, q = lane >> 4;
     const int eb = tid & 15, eu = tid >> 4, unit = k * 16 + eu;
@@ -199,6 +228,8 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
             w[nt][ss] = a.whh[((long)dir * 4 * LH + q * LH + k * 16 + ss) * LH + wave * 64 + nt * 16 + j];
     gu64* ex = (gu64*)(a.ex + (long)cluster * LC_EX_GRANULES);
     constexpr long PAR = 16L * 16 * 256;                              // granules per parity
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ex + (long)cluster * LC_EX_GRANULES), 0,
+                                                                        (int)LC_EX_BYTES, 0x00020000);
     float dc = 0.f;
     for (int n = 0; n < maxlen; ++n) {
         const int s = maxlen - 1 - n;
@@ -252,13 +283,14 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
             }
             __syncthreads();
             // ---- publish the partial dh_{t-1}: element (utterance 4q + r, unit 64w + 16nt + j) -> dest 4w + nt, unit_l j
-            gu64* out = ex + (n & 1) * PAR;
+            // the lane's four utterances 4q .. 4q+3 of one (dest, unit) are four ADJACENT granules: two 16-byte stores
+            const unsigned obase = (unsigned)(((n & 1) * PAR) * 8);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    __hip_atomic_store(out + (((long)(wave * 4 + nt) * 16 + k) * 16 + j) * 16 + 4 * q + r,
-                                       granule((unsigned)(n + 1), acc[nt][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int nt = 0; nt < 4; ++nt) {
+                const unsigned off = obase + (unsigned)((((wave * 4 + nt) * 16 + k) * 16 + j) * 16 + 4 * q) * 8u;
+                store_pair(rsrc, off, granule((unsigned)(n + 1), acc[nt][0]), granule((unsigned)(n + 1), acc[nt][1]));
+                store_pair(rsrc, off + 16, granule((unsigned)(n + 1), acc[nt][2]), granule((unsigned)(n + 1), acc[nt][3]));
+            }
         }
     }
     // frames beyond each utterance: zero pre-activation gradients for this workgroup's 64 gate columns
@@ -284,8 +316,10 @@ int launch_cluster(bool backward, LstmArgs a, void* workspace, int64_t B, hipStr
         // tags restart at 1 in every launch: the exchange area must not hold a previous launch's granules
         if (hipMemsetAsync(a.ex, 0, (size_t)n * 2 * LC_EX_BYTES, stream) != hipSuccess)
             APTAI_FAIL(APTAI_ERR_LAUNCH, "aptai_lstm: hipMemsetAsync of the exchange area failed");
-        if (backward) APTAI_LAUNCH(lstm_cluster_bwd_kernel, dim3((unsigned)(n * 2 * LC_WG)), dim3(256), 0, stream, a);
-        else APTAI_LAUNCH(lstm_cluster_fwd_kernel, dim3((unsigned)(n * 2 * LC_WG)), dim3(256), 0, stream, a);
+        a.nclusters = n * 2;
+        const unsigned grid = 8u * LC_WG * (unsigned)ceil_div(a.nclusters, 8);
+        if (backward) APTAI_LAUNCH(lstm_cluster_bwd_kernel, dim3(grid), dim3(256), 0, stream, a);
+        else APTAI_LAUNCH(lstm_cluster_fwd_kernel, dim3(grid), dim3(256), 0, stream, a);
         APTAI_CHECK_LAUNCH(backward ? "lstm_cluster_bwd_kernel" : "lstm_cluster_fwd_kernel");
     }
     return APTAI_OK;

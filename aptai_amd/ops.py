@@ -537,7 +537,7 @@ def sgemm(a, sam, sak, b, sbk, sbn, M, N, K, *, out=None, ldc=None, bias=None, a
             bsc = M * N
     if split_k is None:
         tiles = ((M + 63) // 64) * ((N + 63) // 64) * batch
-        split_k = 1 if (tiles >= 256 or K < 1024) else max(1, min(K // 256, 512 // tiles))
+        split_k = 1 if (tiles >= 256 or K < 256) else max(1, min(K // 128, 512 // tiles))
     ws = None
     if split_k > 1:
         ws = _scratch_f32("sgemm", batch * split_k * M * N, a.device)
@@ -599,10 +599,11 @@ def layernorm_f32_fwd(x, gamma, beta, eps=1e-5):
 def layernorm_f32_bwd(dy, x, mean, rstd, gamma):
     rows, cols = x.shape
     dx = torch.empty_like(x)
-    dg = torch.zeros(cols, device=x.device, dtype=torch.float32)
-    db = torch.zeros(cols, device=x.device, dtype=torch.float32)
+    dg = torch.empty(cols, device=x.device, dtype=torch.float32)
+    db = torch.empty(cols, device=x.device, dtype=torch.float32)
+    ws = _scratch_f32("ln32_bwd", 256 * 2 * cols, x.device)
     _lib.call("aptai_layernorm_f32_bwd", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-              dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, cols, _stream())
+              dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, cols, _stream())
     return dx, dg, db
 
 

@@ -97,10 +97,15 @@ class Wav2Vec2_PR(nn.Module):
         g, h = out._geom, out._flat_last
         V, H = self.pr_head.weight.shape
         Np = _round_up(V, 64)
-        wp = torch.zeros((Np, H), device=h.device, dtype=torch.bfloat16)
-        ops.cast_bf16(self.pr_head.weight.detach(), wp[:V])
-        bp = torch.zeros(Np, device=h.device, dtype=torch.float32)
-        bp[:V] = self.pr_head.bias.detach()
+
+        def build():
+            wp = torch.zeros((Np, H), device=h.device, dtype=torch.bfloat16)
+            ops.cast_bf16(self.pr_head.weight.detach(), wp[:V])
+            bp = torch.zeros(Np, device=h.device, dtype=torch.float32)
+            bp[:V] = self.pr_head.bias.detach()
+            return wp, bp
+        # padded bf16 head weight: rebuilt only when the parameters moved (eval mode trusts Tensor._version, see _cached)
+        wp, bp = self.wav2vec2._cached(("pr_head_eval",), [self.pr_head.weight, self.pr_head.bias], build)
         full = ops.gemm(h, wp, g.M, Np, H, bias=bp, out_f32=True)
         out._logits_full = full                                   # [B*Tp][Np] fp32: what the device decode reads
         return out, full.view(g.B, g.Tp, Np)[:, :g.T, :V]

@@ -281,7 +281,8 @@ int aptai_xattn_softmax_bwd(const float* att, const float* att_log, const float*
 int aptai_layernorm_f32_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int64_t rows,
                             int64_t cols, float eps, void* stream);
 int aptai_layernorm_f32_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
-                            float* dgamma_zeroed, float* dbeta_zeroed, int64_t rows, int64_t cols, void* stream);
+                            float* dgamma, float* dbeta, float* workspace, int64_t rows, int64_t cols, void* stream);
+int64_t aptai_layernorm_f32_bwd_workspace_bytes(int64_t cols);
 /* nn.LSTM(256,256,bidirectional) over packed sequences (modules.py:195,204-206): xproj [B*Tp][2][1024] = x W_ih^T + b_ih + b_hh,
  * whh [2][1024][256] (weight_hh_l0, weight_hh_l0_reverse as stored), lens int32 [B]; hout [B*Tp][512] (zeros beyond lens);
  * gates (post-activation i,f,g,o) [B*Tp][2][1024] and cstate [B*Tp][2][256] are saved for the backward (both null in

@@ -1,0 +1,100 @@
+"""GPU: BASELINE configs[4] - Force_APTAI on the wav2vec2-LARGE shape with 30-second utterances (S = 480 000 samples, T = 1 499
+frames; K + V of one head no longer fit the LDS).  The reference has no counterpart of this configuration beyond
+"the same code on longer input", so parity is the oracle at reduced depth (2 layers, what the CPU finishes in seconds) and
+size-independent properties at full depth (24 layers)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_gpu_force import _build
+from test_gpu_parity2 import _att_scores, margin_exact
+
+pytestmark = pytest.mark.gpu
+TV = ("LA", "LP", "JA", "TTCL", "TTCD", "TMCL", "TMCD", "TBCL", "TBCD")
+S30 = 480000
+
+
+def _lists(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(2, 40, (int(torch.randint(20, 56, (1,), generator=g)),), generator=g).numpy() for _ in range(B)]
+
+
+def _setup(layers):
+    from aptai_amd.config import W2V2Config
+    from oracle import synth
+    z, meta = load_golden("force_aptai_1x2s")
+    pr_cfg = W2V2Config.from_any(dict(meta["pr_cfg"], num_hidden_layers=layers))
+    assert pr_cfg.hidden_size == 1024 and pr_cfg.do_stable_layer_norm and pr_cfg.feat_extract_norm == "layer"
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, meta["vocab_len"]), meta["seed"])
+    model, _ = _build(dict(meta, pr_cfg=pr_cfg.to_dict()), sd)
+    return model, pr_cfg, sd
+
+
+def test_force_aptai_large_30s_against_the_oracle_at_reduced_depth():
+    from oracle import heads_ref, synth
+    model, pr_cfg, sd = _setup(2)
+    model.train()
+    model.hidden_drop = model.rnn_drop = 0.0
+    batch = synth.synth_aptai_batch(pr_cfg, 2, S30, seed=11, n_phn=40)
+    lists = _lists(2, 3)
+    with torch.no_grad():
+        ref = heads_ref.force_aptai_forward(sd, pr_cfg, batch["audio_inputs"], batch["audio_lengths"], [batch[n] for n in TV],
+                                            phn_pred_list=lists)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    cb["phoneme_labels"] = torch.zeros(2, 4, dtype=torch.int32).cuda()
+    out = model(0, **cb, _phn_pred_list=lists)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert out["tvs_pred"].shape == (2, 1499, 9) and ref["tvs_pred"].shape == (2, 1499, 9)
+    for k in ("loss", "tv_loss", "align_loss"):
+        assert abs(out[k].item() - ref[k].item()) <= 2e-2 * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
+    assert (out["tvs_pred"].cpu() - ref["tvs_pred"]).abs().max().item() <= 4e-2 * ref["tvs_pred"].abs().max().item()
+    # alignment indices over 2 x ~1 400 frames: exact outside the measured noise band
+    with torch.no_grad():
+        res, g, dec = model._run(cb["audio_inputs"], cb["audio_lengths"], phn_pred_list=lists)
+        _, frame_lens, phn_lens, _ = model._lists(dec)
+    att_gpu = res[5].view(g.B, g.Tp, 60)[:, :g.T].float().cpu().numpy()
+    sg, sr = _att_scores(att_gpu, frame_lens, phn_lens), _att_scores(ref["att"].numpy(), frame_lens, phn_lens)
+    ig = np.concatenate([res[8].view(g.B, g.Tp)[b, :t].cpu().numpy() for b, t in enumerate(frame_lens)])
+    ir = np.concatenate([ref["align_idx"][b, :t].numpy() for b, t in enumerate(frame_lens)])
+    eps, frac = margin_exact("force alignment, large, 30 s, 2 layers", ig, ir, sr, sg, max_under=0.12)
+    got_ids = np.concatenate([np.asarray(out["pred_frame_phns"][b]) for b in range(2)])
+    ref_ids = np.concatenate([np.asarray(ref["pred_frame_phns"][b]) for b in range(2)])
+    top2 = np.sort(sr, -1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > eps
+    assert (got_ids[clear] == ref_ids[clear]).all()
+    heads = [(n, p) for n, p in model.named_parameters() if not n.startswith("w2v2_pr.") and p.requires_grad]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in heads)
+
+
+def test_force_aptai_large_30s_full_depth_properties():
+    """24 layers, 2 x 30 s: shapes, finite losses and head gradients, aligned ids drawn from each utterance's own phoneme list,
+    and utterance independence - the first utterance alone gives bit-identical trajectories and alignment (no cross-utterance
+    coupling anywhere on the path, padding included: the second utterance is shorter)."""
+    from oracle import synth
+    model, pr_cfg, _ = _setup(24)
+    model.eval()
+    batch = synth.synth_aptai_batch(pr_cfg, 2, S30, seed=12, n_phn=40)
+    lists = _lists(2, 4)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    cb["phoneme_labels"] = torch.zeros(2, 4, dtype=torch.int32).cuda()
+    with torch.no_grad():
+        out = model(0, **cb, _phn_pred_list=lists)
+        one = model(0, **{k: v[:1] for k, v in cb.items()}, _phn_pred_list=lists[:1])
+    assert out["tvs_pred"].shape == (2, 1499, 9)
+    for k in ("loss", "tv_loss", "align_loss"):
+        assert np.isfinite(out[k].item()), k
+    for b in range(2):
+        assert set(int(v) for v in out["pred_frame_phns"][b]) <= set(int(v) for v in lists[b])
+    n0 = len(out["pred_frame_phns"][0])
+    assert out["pred_frame_phns"][0] == one["pred_frame_phns"][0]
+    # batch 1 runs its LSTM over all frames (models/modules.py:209-212); utterance 0 is full length, so the two agree exactly
+    assert n0 == 1499 and torch.equal(out["tvs_pred"][0], one["tvs_pred"][0])
+    model.train()
+    out = model(0, **cb, _phn_pred_list=lists)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    heads = [(n, p) for n, p in model.named_parameters() if not n.startswith("w2v2_pr.") and p.requires_grad]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in heads)
+    assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("w2v2_pr."))
