@@ -81,6 +81,8 @@ ARGTYPES = {
     "aptai_ctc_bwd": [_P, _I64, _I64, _P, _I64, _P, _P, _P, _I64, _I64, _I64, _I, _I, _I, _P, _P, _P, _F, _P, _I64, _I, _I, _P],
     "aptai_ctc_workspace_bytes": [_I64, _I64, _I64],
     "aptai_ctc_greedy_decode": [_P, _I64, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
+    "aptai_mx_quantize_bf16": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _P],
+    "aptai_gemm_mxfp8": [_P, _P, _I64, _I64, _P, _P, _I64, _I64, _P, _I64, _P, _I, _P, _I64, _I64, _I64, _I64, _P],
     "aptai_device_check": [ctypes.c_char_p, _I],
     "aptai_set_seed_salt": [_P, _P],
 }

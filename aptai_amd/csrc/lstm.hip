@@ -8,14 +8,17 @@
 //   * a cluster = 16 workgroups per (batch group of 16 utterances, direction); workgroup k owns hidden units [16k, 16k+16)
 //     = 64 gate columns, whose W_hh slice (64 KB) lives in REGISTERS for the whole kernel as the B operand of
 //     v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: exact fp32, the M = 16 rows are the 16 utterances);
-//   * per frame every workgroup needs the whole h_{t-1} [16][256]: each publishes its [16][16] slice as 8-byte {tag, value}
-//     granules (one write-through store per lane) into a double-buffered exchange area and sweeps all 4096 granules of the
-//     previous frame until every tag matches (guide, Guideline 16 R2: the data is the flag, no fences, placement-independent);
+//   * per frame every workgroup needs the whole h_{t-1} [16][256]: each publishes its [16][16] slice as self-tagged 4-byte
+//     words (one write-through store per lane) into a double-buffered exchange area and sweeps all 4096 words of the previous
+//     frame (four 16-byte L1-bypassing loads per thread) until every tag matches (guide, Guideline 16 R2: the data is the flag,
+//     no fences, placement-independent).  The tag is ONE bit inside the float: |h| <= 1 leaves bit 30 of its fp32 pattern
+//     clear, so the forward stores the tag there losslessly; the backward's partial sums give up their mantissa LSB (<= 1 ulp).
+//     One bit suffices because a buffer is rewritten every second frame and its tag flips between consecutive rewrites
+//     (tau(s) = ((s >> 1) & 1) ^ 1; the area is zeroed before every launch, so the first writes already differ);
 //   * backward: workgroup k forms the pre-activation gradients of its own 64 gate columns, multiplies them with its W_hh rows
 //     ([16 x 64] . [64 x 256]) and publishes the partial dh_{t-1} [16][256]; every workgroup sums the 16 partials of its own
 //     units in workgroup order (deterministic).
-// Tags count frames within one launch (1..T) and the exchange area is zeroed by a memset node ahead of every launch, so a
-// replayed hipGraph is safe.  Every spin is bounded; a timeout raises the status word at the end of the workspace.
+// The exchange area is zeroed by a memset node ahead of every launch, so a replayed hipGraph is safe.  Every spin is bounded; a timeout raises the status word at the end of the workspace.
 // All 16 workgroups of a cluster must be resident together: a launch holds at most 12 clusters = 192 workgroups of one wave
 // per SIMD on a 256-CU chip.
 #include "common.h"
@@ -51,23 +54,16 @@ __device__ __forceinline__ float quad_pick(const f32x4& acc, int slot) {  // reg
     const float v0 = quad_bcast<SRC>(acc[0]), v1 = quad_bcast<SRC>(acc[1]), v2 = quad_bcast<SRC>(acc[2]), v3 = quad_bcast<SRC>(acc[3]);
     return slot == 0 ? v0 : slot == 1 ? v1 : slot == 2 ? v2 : v3;
 }
-__device__ __forceinline__ u64 granule(unsigned tag, float v) { return ((u64)tag << 32) | (u64)__float_as_uint(v); }
-
-// sweep N granules (stride `stride` u64 from `src`) until every tag equals `tag`; false on timeout
-template <int N>
-__device__ __forceinline__ bool sweep(const gu64* src, long stride, unsigned tag, u64 (&g)[N], unsigned* status) {
-    for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int r = 0; r < N; ++r) {
-            g[r] = __hip_atomic_load(src + r * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok &= (unsigned)(g[r] >> 32) == tag;
-        }
-        if (__all(ok)) return true;
-        if (spins > LC_SPIN_LIMIT) {
-            if ((threadIdx.x & 63) == 0) atomicExch(status, 1u);
-            return false;
-        }
+__device__ __forceinline__ unsigned tau(int step) { return (((unsigned)step >> 1) & 1u) ^ 1u; }
+// forward words: tag in bit 30 (clear for every |v| < 2); backward words: tag in the mantissa LSB
+__device__ __forceinline__ unsigned word30(unsigned tag, float v) { return (__float_as_uint(v) & ~(1u << 30)) | (tag << 30); }
+__device__ __forceinline__ unsigned word0(unsigned tag, float v) { return (__float_as_uint(v) & ~1u) | tag; }
+// aux = 16: sc1 (write-through store / L1-bypassing load) on the raw buffer instructions (guide, Guideline 16 R1)
+__device__ __forceinline__ void spin_or_fail(unsigned& spins, unsigned* status) {
+    if (++spins > LC_SPIN_LIMIT) {
+        if ((threadIdx.x & 63) == 0) atomicExch(status, 1u);
+        spins = 0x80000000u;                                         // tells the caller to give up
+    } else {
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -121,7 +117,8 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
     const int myrow = 4 * q + gate, myb = bg * 16 + myrow;            // the (utterance, unit) this lane finalises
     const int mylen = gate == 0 ? lenr[0] : gate == 1 ? lenr[1] : gate == 2 ? lenr[2] : lenr[3];
     float c_st = 0.f, h_st = 0.f;
-    gu64* ex = (gu64*)(a.ex + (long)cluster * LC_EX_GRANULES);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ex + (long)cluster * LC_EX_GRANULES), 0,
+                                                                        (int)LC_EX_BYTES, 0x00020000);
 
     for (int s = 0; s < maxlen; ++s) {
         f32x4 acc;
@@ -132,14 +129,30 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
             acc[r] = s < lenr[r] ? a.xproj[(((long)b * a.Tp + t) * 2 + dir) * 4 * LH + col] : 0.f;
         }
         if (s > 0) {
-            // ---- gather h_{s-1}: granule (unit u, batch i) at u*16 + i; thread reads idx = r*256 + tid -> u = r*16 + (tid >> 4), i = tid & 15
-            u64 g[16];
-            sweep<16>(ex + ((s - 1) & 1) * 4096 + tid, 256, (unsigned)s, g, a.status);
+            // ---- gather h_{s-1}: word (unit u, batch i) at u*16 + i.  Thread reads the 16-byte pieces L = r*256 + tid, r = 0..3:
+            // unit u = r*64 + (tid >> 2), batches 4 (tid & 3) .. + 3
+            const unsigned want = tau(s - 1);
+            const unsigned gbase = (unsigned)(((s - 1) & 1) * 4096 * 4) + (unsigned)tid * 16u;
+            u32x4 g[4];
+            for (unsigned spins = 0;;) {
+                bool ok = true;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // element (i, u): MFMA image word = c*256 + (qq*16 + i)*4 + e with qq = u >> 6, c = (u & 63) >> 2, e = u & 3
-                const int c = (r & 3) * 4 + wave, qq = r >> 2, e = (lane >> 4) & 3, i = lane & 15;
-                hs[c * 256 + (qq * 16 + i) * 4 + e] = __uint_as_float((unsigned)g[r]);
+                for (int r = 0; r < 4; ++r) {
+                    g[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, gbase + (unsigned)r * 4096u, 0, 16);
+                    ok &= ((g[r][0] >> 30) & 1u) == want && ((g[r][1] >> 30) & 1u) == want && ((g[r][2] >> 30) & 1u) == want &&
+                          ((g[r][3] >> 30) & 1u) == want;
+                }
+                if (__all(ok)) break;
+                spin_or_fail(spins, a.status);
+                if (spins == 0x80000000u) break;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // element (i, u): MFMA image word = c*256 + (qq*16 + i)*4 + e with qq = u >> 6 = r, c = (u & 63) >> 2 = tid >> 4,
+                // e = u & 3 = (tid >> 2) & 3
+                const int base = (tid >> 4) * 256 + (r * 16 + 4 * (tid & 3)) * 4 + ((tid >> 2) & 3);
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) hs[base + 4 * e4] = __uint_as_float(g[r][e4] & ~(1u << 30));
             }
             __syncthreads();
             // two accumulator chains: a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one issues after 32
@@ -162,8 +175,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
         const float h_new = go * tanhf(c_new);
         const bool act = s < mylen;
         if (act) { c_st = c_new; h_st = h_new; }
-        __hip_atomic_store(ex + (s & 1) * 4096 + unit * 16 + myrow, granule((unsigned)(s + 1), h_st), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_raw_buffer_store_b32(word30(tau(s), h_st), rsrc, (unsigned)(((s & 1) * 4096 + unit * 16 + myrow) * 4), 0, 16);
         if (act) {
             const int t = dir ? mylen - 1 - s : s;
             const long row = (long)myb * a.Tp + t;
@@ -183,19 +195,6 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
         l = l < a.T ? l : a.T;
         for (int t = l + (tid >> 4); t < a.Tp; t += 16) a.hout[((long)b * a.Tp + t) * 2 * LH + dir * LH + k * 16 + (tid & 15)] = 0.f;
     }
-}
-
-// 16-byte write-through store / L1-bypassing load of TWO adjacent granules (guide, Guideline 16 R1: sc1 stores, sc1 loads; a
-// 16-byte sc1 access was observed untorn per 8-byte half on gfx950, and every granule carries its own tag, so a torn pair
-// would only make the sweep retry).  aux = 16 selects sc1 on the raw buffer instructions.
-__device__ __forceinline__ void store_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, u64 g0, u64 g1) {
-    const u32x4 v = {(uint32_t)g0, (uint32_t)(g0 >> 32), (uint32_t)g1, (uint32_t)(g1 >> 32)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, byte_off, 0, 16);
-}
-__device__ __forceinline__ void load_pair(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, u64& g0, u64& g1) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);
-    g0 = ((u64)v[1] << 32) | v[0];
-    g1 = ((u64)v[3] << 32) | v[2];
 }
 
 // ================================================================================================ backward through time
@@ -226,8 +225,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
 #pragma unroll
         for (int ss = 0; ss < 16; ++ss)
             w[nt][ss] = a.whh[((long)dir * 4 * LH + q * LH + k * 16 + ss) * LH + wave * 64 + nt * 16 + j];
-    gu64* ex = (gu64*)(a.ex + (long)cluster * LC_EX_GRANULES);
-    constexpr long PAR = 16L * 16 * 256;                              // granules per parity
+    constexpr long PAR = 16L * 16 * 256;                              // words per parity
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ex + (long)cluster * LC_EX_GRANULES), 0,
                                                                         (int)LC_EX_BYTES, 0x00020000);
     float dc = 0.f;
@@ -247,10 +245,22 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
         float dh_rec = 0.f;
         if (n > 0) {
             // partial sums of iteration n-1 for this workgroup's units: [src 16][unit_l 16][batch 16], thread = (eu, eb)
-            u64 g[16];
-            sweep<16>(ex + ((n - 1) & 1) * PAR + (long)k * 16 * 256 + tid, 256, (unsigned)n, g, a.status);
+            const unsigned want = tau(n - 1);
+            const unsigned gbase = (unsigned)((((n - 1) & 1) * PAR + (long)k * 16 * 256 + tid) * 4);
+            unsigned g[16];
+            for (unsigned spins = 0;;) {
+                bool ok = true;
 #pragma unroll
-            for (int src = 0; src < 16; ++src) dh_rec += __uint_as_float((unsigned)g[src]);
+                for (int src = 0; src < 16; ++src) {
+                    g[src] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, gbase + (unsigned)src * 1024u, 0, 16);
+                    ok &= (g[src] & 1u) == want;
+                }
+                if (__all(ok)) break;
+                spin_or_fail(spins, a.status);
+                if (spins == 0x80000000u) break;
+            }
+#pragma unroll
+            for (int src = 0; src < 16; ++src) dh_rec += __uint_as_float(g[src] & ~1u);
         }
         float pi = 0.f, pf = 0.f, pg = 0.f, po = 0.f;
         if (act) {
@@ -283,13 +293,14 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
             }
             __syncthreads();
             // ---- publish the partial dh_{t-1}: element (utterance 4q + r, unit 64w + 16nt + j) -> dest 4w + nt, unit_l j
-            // the lane's four utterances 4q .. 4q+3 of one (dest, unit) are four ADJACENT granules: two 16-byte stores
-            const unsigned obase = (unsigned)(((n & 1) * PAR) * 8);
+            // the lane's four utterances 4q .. 4q+3 of one (dest, unit) are four ADJACENT words: one 16-byte store
+            const unsigned t = tau(n);
+            const unsigned obase = (unsigned)(((n & 1) * PAR) * 4);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const unsigned off = obase + (unsigned)((((wave * 4 + nt) * 16 + k) * 16 + j) * 16 + 4 * q) * 8u;
-                store_pair(rsrc, off, granule((unsigned)(n + 1), acc[nt][0]), granule((unsigned)(n + 1), acc[nt][1]));
-                store_pair(rsrc, off + 16, granule((unsigned)(n + 1), acc[nt][2]), granule((unsigned)(n + 1), acc[nt][3]));
+                const unsigned off = obase + (unsigned)((((wave * 4 + nt) * 16 + k) * 16 + j) * 16 + 4 * q) * 4u;
+                const u32x4 v = {word0(t, acc[nt][0]), word0(t, acc[nt][1]), word0(t, acc[nt][2]), word0(t, acc[nt][3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16);
             }
         }
     }

@@ -264,6 +264,12 @@ class Force_APTAI(nn.Module):
         return {'loss': loss, 'tv_loss': tv_loss, 'align_loss': align_loss, 'tvs_pred': tvs,
                 'pred_frame_phns': pred_frame_phns, 'pred_ctc_phn_seq': phn_pred_list}
 
+    def set_encoder_precision(self, precision: str = "bf16"):
+        """"mxfp8": the frozen recogniser's transformer Linear layers run with MX block-scaled FP8 operands (BASELINE configs[4]);
+        the heads stay fp32.  See Wav2Vec2Model.set_encoder_precision."""
+        self.w2v2_pr.wav2vec2.set_encoder_precision(precision)
+        return self
+
     def get_config(self):
         return {'pr_model_path': self.pr_model_path, 'w2v2_pr_cfg': self.w2v2_pr_cfg, 'device': self.device, 'vocab': self.vocab}
 

@@ -186,6 +186,31 @@ def ones_kmajor(K: int, device) -> torch.Tensor:
     return t
 
 
+# ----------------------------------------------------------------------------- MX block-scaled FP8 (inference-only encoder)
+def mx_quantize(x: torch.Tensor, out=None):
+    """bf16 [rows][K] -> (q uint8 [rows][K], scales uint8 [rows][K/32]) in OCP MXFP8 (E4M3 elements, E8M0 block scales)."""
+    _dev(x)
+    rows, K = x.shape
+    if out is None:
+        q = torch.empty((rows, K), device=x.device, dtype=torch.uint8)
+        s = torch.empty((rows, K // 32), device=x.device, dtype=torch.uint8)
+    else:
+        q, s = out
+    _lib.call("aptai_mx_quantize_bf16", x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), s.data_ptr(), s.stride(0), rows, K, _stream())
+    return q, s
+
+
+def gemm_mxfp8(aq, a_s, bq, b_s, M, N, K, *, bias=None, gelu=False, residual=None, out=None):
+    """C bf16 [M][N] = dequant(A) . dequant(B)^T + bias [-> GELU] [+ residual] (aptai_gemm_mxfp8)."""
+    _dev(aq, a_s, bq, b_s, bias, residual, out)
+    if out is None:
+        out = torch.empty((M, N), device=aq.device, dtype=torch.bfloat16)
+    _lib.call("aptai_gemm_mxfp8", aq.data_ptr(), a_s.data_ptr(), aq.stride(0), a_s.stride(0), bq.data_ptr(), b_s.data_ptr(), bq.stride(0),
+              b_s.stride(0), out.data_ptr(), out.stride(0), _ptr(bias), int(gelu), _ptr(residual), residual.stride(0) if residual is not None else 0,
+              M, N, K, _stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- LayerNorm
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), device=device, dtype=torch.uint8)

@@ -129,6 +129,9 @@ class _LayerImpl:
         p_att = cfg.attention_dropout if tr else 0.0
         s = SimpleNamespace(x=x)
         pre = cfg.do_stable_layer_norm
+        mx = getattr(self, "mx", None)
+        if mx is not None and not need:
+            return self._fwd_mxfp8(x, params, mx)
         if pre:
             n1, s.m1, s.r1 = ops.layernorm_fwd(x, ln1w, ln1b, cfg.layer_norm_eps, save_stats=need)
             attn_in = n1
@@ -158,6 +161,31 @@ class _LayerImpl:
         s.p = (p_h, p_a, p_att)
         s.ln = (ln1w, ln1b, ln2w, ln2b)
         return (y,), (s if need else None)
+
+    def _fwd_mxfp8(self, x, params, mx):
+        """Inference-only forward with MX block-scaled FP8 operands in the four Linear layers (BASELINE configs[4]; csrc/mxgemm.hip):
+        every GEMM input is quantised on the fly (E4M3 elements, E8M0 scale per 32 k), the frozen weights were quantised once;
+        LayerNorm, attention, biases, residual stream and accumulation are as in the bf16 path."""
+        cfg, g, w = self.cfg, self.g, self.w
+        M, H, I = g.M, cfg.hidden_size, cfg.intermediate_size
+        ln1w, ln1b, ln2w, ln2b = params[0], params[1], params[2], params[3]
+        pre = cfg.do_stable_layer_norm
+        attn_in = ops.layernorm_fwd(x, ln1w, ln1b, cfg.layer_norm_eps, save_stats=False)[0] if pre else x
+        aq, a_s = ops.mx_quantize(attn_in)
+        qkv = ops.gemm_mxfp8(aq, a_s, mx.wqkv[0], mx.wqkv[1], M, 3 * H, H, bias=w.bqkv)
+        ctx, _ = ops.attention_fwd(qkv, self.lens, g.B, g.Tp, H, cfg.num_attention_heads, save_lse=False)
+        cq, c_s = ops.mx_quantize(ctx)
+        s1 = ops.gemm_mxfp8(cq, c_s, mx.wo[0], mx.wo[1], M, H, H, bias=w.bo, residual=x)
+        if pre:
+            ffn_in = ops.layernorm_fwd(s1, ln2w, ln2b, cfg.layer_norm_eps, save_stats=False)[0]
+        else:
+            ffn_in = ops.layernorm_fwd(s1, ln1w, ln1b, cfg.layer_norm_eps, save_stats=False)[0]
+        fq, f_s = ops.mx_quantize(ffn_in)
+        hact = ops.gemm_mxfp8(fq, f_s, mx.w1[0], mx.w1[1], M, I, H, bias=w.b1, gelu=True)
+        hq, h_s = ops.mx_quantize(hact)
+        s2 = ops.gemm_mxfp8(hq, h_s, mx.w2[0], mx.w2[1], M, H, I, bias=w.b2, residual=s1 if pre else ffn_in)
+        y = s2 if pre else ops.layernorm_fwd(s2, ln2w, ln2b, cfg.layer_norm_eps, save_stats=False)[0]
+        return (y,), None
 
     def bwd(self, s, grads, x_needs):
         """dgrad chain on the caller's stream; the weight/bias gradients are independent of that chain and can go to a side
@@ -497,6 +525,25 @@ class Wav2Vec2Model(nn.Module):
         from safetensors.torch import save_file
         save_file({k: v.contiguous() for k, v in self.state_dict().items()}, os.path.join(path, "model.safetensors"))
 
+    def set_encoder_precision(self, precision: str = "bf16"):
+        """"bf16" (default) or "mxfp8": the latter runs the Linear layers of the transformer stack with OCP MXFP8 operands on the
+        block-scaled matrix instruction - INFERENCE ONLY (eval mode, no gradients: the frozen recogniser inside Force_APTAI,
+        BASELINE configs[4]); any forward that needs gradients keeps the bf16 kernels."""
+        if precision not in ("bf16", "mxfp8"):
+            raise ValueError("encoder precision must be 'bf16' or 'mxfp8'")
+        self._encoder_precision = precision
+        return self
+
+    def _mx_layer_weights(self, i: int):
+        """MXFP8 copies (elements, scales) of layer i's four weight matrices, quantised from the bf16 compute copies; rebuilt only
+        when the parameters moved (eval mode trusts Tensor._version, see _cached)."""
+        e = self._layer_plan().entries[i]
+
+        def build():
+            return SimpleNamespace(wqkv=ops.mx_quantize(e.wqkv), wo=ops.mx_quantize(e.wo), w1=ops.mx_quantize(e.w1),
+                                   w2=ops.mx_quantize(e.w2))
+        return self._cached(("mx", i), self._layer_params(i), build)
+
     def gradient_checkpointing_enable(self, *a, **kw):
         """Accepted for drop-in compatibility (models/aptai.py:38): 288 GB of HBM make recomputation unnecessary."""
         return None
@@ -813,6 +860,8 @@ class Wav2Vec2Model(nn.Module):
                 continue
             w, lin_params = self._layer_weights(i, g.M)
             impl = _LayerImpl(cfg, g, lens_i32, w, training, _seed(seed, 100 + i))
+            if getattr(self, "_encoder_precision", "bf16") == "mxfp8" and not training:
+                impl.mx = self._mx_layer_weights(i)
             h = _run(impl, h, layer.layer_norm.weight, layer.layer_norm.bias, layer.final_layer_norm.weight,
                             layer.final_layer_norm.bias, *lin_params)
         if cfg.do_stable_layer_norm:

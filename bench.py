@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of aptai_amd.optim.Adam")
     ap.add_argument("--host-batch", action="store_true", help="hand the step a pinned HOST batch every iteration (PCIe-inclusive rate; "
                     "never the headline value: DESIGN.md section 8)")
+    ap.add_argument("--encoder-precision", default="bf16", choices=["bf16", "mxfp8"],
+                    help="force workload: precision of the frozen encoder's Linear layers (mxfp8 = BASELINE configs[4])")
     ap.add_argument("--eager", action="store_true", help="drive the step through autograd (the drop-in loop) instead of hipGraphs")
     return ap.parse_args()
 
@@ -368,6 +370,7 @@ def main():
         call = lambda: model(**batch)
     else:
         model, cfg = build_force(args, device)
+        model.set_encoder_precision(args.encoder_precision)
         w2v2 = model.w2v2_pr.wav2vec2
         batch = synth_batch(cfg, B, S, 9, rank, device, n_phn=40)
         batch["phoneme_labels"] = synth_ctc_labels(B, 40, rank, device)
@@ -512,7 +515,8 @@ def main():
             "metric": "utterances/sec (10 s @ 16 kHz) train-step", "value": round(world * B * args.steps / dt, 3),
             "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": data_note,
+            "vs_baseline": None, "dtype": "bf16" if (wl != "force" or args.encoder_precision == "bf16") else "mxfp8 (E4M3 + E8M0 block scales) in the encoder's Linear layers, bf16 elsewhere, fp32 heads",
+            "data": data_note,
             "config": {"workload": what,
                        "per_gpu_batch": B, "global_batch": world * B, "clip_seconds": args.seconds,
                        "parallelism": f"dp{world}", "ranks": world,

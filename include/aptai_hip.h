@@ -223,6 +223,19 @@ int aptai_aptai_loss_bwd(const float* tv_pred, const float* tv_tgt, const float*
                          void* stream);
 int64_t aptai_aptai_loss_workspace_bytes(void);
 
+/* ------------------------------------------------------------------------------------------------ MX block-scaled FP8 GEMM
+ * BASELINE configs[4] ("fp8 MFMA weights"): the frozen, inference-only encoder of Force_APTAI with OCP MXFP8 operands - E4M3
+ * elements, one E8M0 scale per 32 consecutive k - on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 MFMA rate on gfx950; no
+ * reference counterpart: the reference is fp32).  aptai_mx_quantize_bf16: x bf16 [rows][K] -> q (1 byte / element,
+ * row stride ldq) + scales (1 byte per 32 k, row stride lds); scale = 2^(floor(log2 amax) - 8), elements round-to-nearest-even,
+ * saturated to +-448.  aptai_gemm_mxfp8: C bf16 [M][N] = dequant(A) . dequant(B)^T + bias, optional GELU, + residual;
+ * replaces nn.Linear of the encoder layers (HF:495-498,546,556-572) when the model is switched to "mxfp8" inference. */
+int aptai_mx_quantize_bf16(const void* x, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t lds, int64_t rows, int64_t K,
+                           void* stream);
+int aptai_gemm_mxfp8(const void* A, const void* A_scales, int64_t lda, int64_t ldas, const void* B, const void* B_scales, int64_t ldb,
+                     int64_t ldbs, void* C, int64_t ldc, const float* bias, int gelu, const void* residual, int64_t ldr, int64_t M,
+                     int64_t N, int64_t K, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ CTC
  * log_softmax + CTC negative log-likelihood (alpha recursion) and its gradient w.r.t. the LOGITS (beta recursion),
  * replacing nn.functional.log_softmax + F.ctc_loss at models/w2v2_pr.py:59,73-81 and the per-sample nn.CTCLoss loop

@@ -1,0 +1,108 @@
+"""GPU: the MX block-scaled FP8 path of BASELINE configs[4] (csrc/mxgemm.hip).  No reference counterpart exists (the reference
+is fp32), so the checks are against the OCP MX definition restated on the CPU: quantiser bytes exact, GEMM equal to
+the product of the DE-QUANTISED operands up to bf16 output rounding, and the encoder switched to "mxfp8" close to its bf16 self."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _quant_ref(x):
+    """OCP MXFP8 (E4M3) quantisation of a [rows][K] fp32 tensor: per 32-block scale 2^(floor(log2 amax) - 8), elements RNE,
+    saturated to +-448.  Returns (uint8 element codes, uint8 E8M0 scales, dequantised fp32)."""
+    rows, K = x.shape
+    xb = x.view(rows, K // 32, 32)
+    amax = xb.abs().amax(-1)
+    e = torch.floor(torch.log2(amax.clamp(min=1e-38))).to(torch.int32) - 8 + 127
+    e = e.clamp(1, 254)
+    e = torch.where(amax == 0, torch.ones_like(e), e)
+    scale = torch.pow(2.0, (e - 127).float())[..., None]
+    q8 = (xb / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    deq = (q8.float() * scale).view(rows, K)
+    return q8.view(torch.uint8).view(rows, K), e.to(torch.uint8), deq
+
+
+def test_mx_quantiser_matches_the_ocp_definition():
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(300, 256, generator=g) * torch.exp(torch.randn(300, 1, generator=g) * 3)).to(torch.bfloat16)
+    x[5, 32:64] = 0.0                                            # an all-zero block
+    x[7, 0] = 3.0e4                                              # a large outlier inside a block
+    q, s = ops.mx_quantize(x.cuda())
+    q_ref, s_ref, _ = _quant_ref(x.float())
+    assert torch.equal(s.cpu(), s_ref)
+    got, want = q.cpu(), q_ref
+    nz = ~((got == want) | ((got & 0x7F) == 0) & ((want & 0x7F) == 0))           # +0 and -0 both encode zero
+    assert not nz.any(), f"{int(nz.sum())} element codes differ"
+
+
+@pytest.mark.parametrize("M,N,K,gelu,res", [(256, 384, 256, False, False), (300, 768, 768, True, False), (8192, 768, 3072, False, True)])
+def test_mx_gemm_equals_the_product_of_the_dequantised_operands(M, N, K, gelu, res):
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16) if res else None
+    aq, a_s = ops.mx_quantize(a.cuda())
+    wq, w_s = ops.mx_quantize(w.cuda())
+    out = ops.gemm_mxfp8(aq, a_s, wq, w_s, M, N, K, bias=bias.cuda(), gelu=gelu, residual=r.cuda() if res else None).float().cpu()
+    _, _, a_d = _quant_ref(a.float())
+    _, _, w_d = _quant_ref(w.float())
+    ref = (a_d.double() @ w_d.double().t()).float() + bias
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + r.float()
+    err = (out - ref).abs().max().item()
+    assert err <= 1e-2 * ref.abs().max().item() + 1e-3, (err, ref.abs().max().item())          # bf16 output rounding
+    # and the quantisation error itself stays at the E4M3 level against the unquantised product
+    full = (a.double() @ w.double().t()).float() + bias
+    if not gelu and not res:
+        rel = ((ref - full).norm() / full.norm()).item()
+        assert rel < 6e-2, rel
+
+
+def test_force_aptai_with_the_mxfp8_encoder_against_the_oracle():
+    """Force_APTAI (large shape, reduced depth) with the frozen encoder's Linear layers in MXFP8: the same gate as the bf16 path -
+    alignment indices exact wherever the oracle's margin exceeds the measured row noise - with the fraction of frames inside the
+    (wider) noise band reported; trajectories and losses within the E4M3 error level; training the heads still works."""
+    from test_gpu_config5 import _setup, _lists, TV
+    from test_gpu_parity2 import _att_scores, margin_exact
+    from oracle import heads_ref, synth
+    model, pr_cfg, sd = _setup(2)
+    model.set_encoder_precision("mxfp8")
+    model.train()
+    model.hidden_drop = model.rnn_drop = 0.0
+    batch = synth.synth_aptai_batch(pr_cfg, 2, 48000, seed=13, n_phn=40)
+    lists = _lists(2, 5)
+    with torch.no_grad():
+        ref = heads_ref.force_aptai_forward(sd, pr_cfg, batch["audio_inputs"], batch["audio_lengths"], [batch[n] for n in TV],
+                                            phn_pred_list=lists)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    cb["phoneme_labels"] = torch.zeros(2, 4, dtype=torch.int32).cuda()
+    out = model(0, **cb, _phn_pred_list=lists)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    # the bf16 run of the same model, for scale
+    model.set_encoder_precision("bf16")
+    with torch.no_grad():
+        out16 = model(0, **cb, _phn_pred_list=lists)
+    model.set_encoder_precision("mxfp8")
+    e8 = (out["tvs_pred"].cpu() - ref["tvs_pred"]).abs().max().item() / ref["tvs_pred"].abs().max().item()
+    e16 = (out16["tvs_pred"].cpu() - ref["tvs_pred"]).abs().max().item() / ref["tvs_pred"].abs().max().item()
+    print(f"[mxfp8] max |tvs_pred - oracle| / max|oracle|: mxfp8 {e8:.4f}, bf16 {e16:.4f}")
+    assert e8 <= 0.25 and e8 > e16 * 0.5                          # a real fp8 run (not the bf16 kernels), at the E4M3 error level
+    for k in ("loss", "tv_loss", "align_loss"):
+        assert abs(out[k].item() - ref[k].item()) <= 0.1 * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
+    with torch.no_grad():
+        res, g, dec = model._run(cb["audio_inputs"], cb["audio_lengths"], phn_pred_list=lists)
+        _, frame_lens, phn_lens, _ = model._lists(dec)
+    att_gpu = res[5].view(g.B, g.Tp, 60)[:, :g.T].float().cpu().numpy()
+    sg, sr = _att_scores(att_gpu, frame_lens, phn_lens), _att_scores(ref["att"].numpy(), frame_lens, phn_lens)
+    ig = np.concatenate([res[8].view(g.B, g.Tp)[b, :t].cpu().numpy() for b, t in enumerate(frame_lens)])
+    ir = np.concatenate([ref["align_idx"][b, :t].numpy() for b, t in enumerate(frame_lens)])
+    margin_exact("force alignment, mxfp8 encoder", ig, ir, sr, sg, max_under=0.5)
+    heads = [(n, p) for n, p in model.named_parameters() if not n.startswith("w2v2_pr.") and p.requires_grad]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in heads)

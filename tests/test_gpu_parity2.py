@@ -25,24 +25,27 @@ TV = ("LA", "LP", "JA", "TTCL", "TTCD", "TMCL", "TMCD", "TBCL", "TBCD")
 
 
 def margin_exact(name, got_idx, ref_idx, ref_scores, got_scores, max_under=0.08, max_dev=None):
-    """Exact equality of argmax indices wherever the oracle's top-2 margin exceeds eps = 2 * max|got_scores - ref_scores|.
-    Returns (eps, fraction of decisions under eps)."""
+    """Exact equality of argmax indices on every decision (row) whose oracle top-2 margin exceeds eps_row = 2 x the largest
+    score deviation IN THAT ROW: two scores can only swap order if they move toward each other by more than their gap, so on
+    those rows any mismatch is an indexing error, not arithmetic noise.  Returns (largest eps_row, fraction of rows under eps)."""
     ref_scores, got_scores = np.asarray(ref_scores, np.float64), np.asarray(got_scores, np.float64)
-    dev = float(np.abs(got_scores - ref_scores).max())
+    ref_scores = ref_scores.reshape(-1, ref_scores.shape[-1])
+    got_scores = got_scores.reshape(ref_scores.shape)
+    dev_row = np.abs(got_scores - ref_scores).max(axis=-1)
+    dev = float(dev_row.max())
     if max_dev is not None:
         assert dev <= max_dev, f"{name}: scores deviate by {dev:.4f} > {max_dev}"
-    eps = 2.0 * dev
     top2 = np.sort(ref_scores, axis=-1)[..., -2:]
     margin = top2[..., 1] - top2[..., 0]
-    clear = margin > eps
-    got_idx, ref_idx = np.asarray(got_idx), np.asarray(ref_idx)
+    clear = margin > 2.0 * dev_row
+    got_idx, ref_idx = np.asarray(got_idx).reshape(-1), np.asarray(ref_idx).reshape(-1)
     bad = (got_idx != ref_idx) & clear
     frac = 1.0 - float(clear.mean())
-    print(f"[margin] {name}: max score deviation {dev:.4f}, eps {eps:.4f}, {frac * 100:.2f} % of {clear.size} decisions under eps, "
-          f"{int((got_idx != ref_idx).sum())} differ in total")
-    assert not bad.any(), f"{name}: {int(bad.sum())} index mismatches on clear-margin decisions (eps {eps:.4f})"
-    assert frac <= max_under, f"{name}: {frac:.3f} of the decisions sit under eps {eps:.4f}"
-    return eps, frac
+    print(f"[margin] {name}: max score deviation {dev:.4f} (median row {np.median(dev_row):.4f}), {frac * 100:.2f} % of {clear.size} "
+          f"decisions under their row's eps, {int((got_idx != ref_idx).sum())} differ in total")
+    assert not bad.any(), f"{name}: {int(bad.sum())} index mismatches on clear-margin decisions"
+    assert frac <= max_under, f"{name}: {frac:.3f} of the decisions sit under eps"
+    return 2.0 * dev_row, frac
 
 
 # ------------------------------------------------------------------------------------------------ SpecAugment
@@ -204,7 +207,7 @@ def test_pr_inference_helpers_against_the_oracle():
     eps, frac = margin_exact("pr frame argmax", lg.argmax(-1), rl.argmax(-1), rl, lg, max_under=0.15)
     ref_ids = heads_ref.ctc_best_path(rl)
     top2 = np.sort(rl, -1)[:, -2:]
-    all_clear = bool(((top2[:, 1] - top2[:, 0]) > eps).all())
+    all_clear = bool(((top2[:, 1] - top2[:, 0]) > eps).all())                 # eps: per-frame vector
     vocab = model.vocab
     got = model.pred_phn_seq(wav, vocab)
     inv = {v: k for k, v in vocab.items()}
@@ -293,7 +296,7 @@ def test_force_alignment_indices_exact_outside_the_measured_noise():
     n = len(z["b1/pred_ctc_phn_seq"])
     sr1 = _att_scores(ro["att"].numpy(), [len(z["b1/pred_frame_phns"])], [n])
     t2 = np.sort(sr1, -1)[:, -2:]
-    clear1 = (t2[:, 1] - t2[:, 0]) > eps
+    clear1 = (t2[:, 1] - t2[:, 0]) > float(np.max(eps))          # no GPU scores for this run: the B = 2 run's largest row eps
     got1 = np.asarray(out["pred_frame_phns"][0])
     assert (got1[clear1] == z["b1/pred_frame_phns"][clear1]).all()
     print(f"[margin] force alignment B=1 vs reference fixture: {100 * (1 - clear1.mean()):.2f} % of {clear1.size} frames under eps, "

@@ -1,0 +1,14 @@
+#!/bin/bash
+set -eo pipefail
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/r2f
+mkdir -p "$O"
+cd "$R"
+timeout -k 10 1100 python -m pytest tests/test_gpu_mxfp8.py tests/test_gpu_config5.py tests/test_gpu_parity2.py -m gpu -q -x -s > "$O/pytest.log" 2>&1 || { grep -E "margin\]|mxfp8\]|FAILED|Error|assert|error" "$O/pytest.log" | head -60; exit 1; }
+grep -E "margin\]|mxfp8\]|passed|failed" "$O/pytest.log" | tail -14
+for prec in bf16 mxfp8; do
+  timeout -k 10 300 python bench.py --workload force --encoder-precision $prec --steps 10 --warmup 3 --no-cpu-baseline > "$O/force_$prec.json" 2> "$O/force.err" || { tail -30 "$O/force.err"; exit 1; }
+  echo "$prec $(cut -c1-200 "$O/force_$prec.json")"
+done
+timeout -k 10 300 python bench.py --workload pr --steps 10 --warmup 3 --no-cpu-baseline > "$O/pr.json" 2> "$O/pr.err" || { tail -30 "$O/pr.err"; exit 1; }
+cut -c1-260 "$O/pr.json"
