@@ -221,3 +221,74 @@ def match_phonemes_to_frames(phoneme_boundaries, phoneme_list, frame_duration: f
         out.append(current)
     return out
 
+
+
+# ----------------------------------------------------------------------------- input pipeline: 16 kHz resample + crop (f-4)
+def resample(waveform, orig_freq: int, new_freq: int = 16000, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """`torchaudio.functional.resample(waveform, orig_freq, new_freq)` as data/dataset_commonphone.py:31-33 calls it (wav2vec2
+    was pre-trained on 16 kHz audio): band-limited sinc interpolation with a Hann window (torchaudio's default
+    `sinc_interp_hann`, lowpass_filter_width 6, rolloff 0.99), restated from the published algorithm - torchaudio is not in this
+    image, so parity with it is unpinned; the test pins the properties (length, DC gain, a tone keeps its frequency, identity).
+    waveform: 1-D or (channels, time) array / tensor; returns a float32 tensor of the same rank."""
+    import math
+    w = torch.as_tensor(np.asarray(waveform), dtype=torch.float32) if not torch.is_tensor(waveform) else waveform.float()
+    squeeze = w.dim() == 1
+    w = w.reshape(1, -1) if squeeze else w.reshape(-1, w.shape[-1])
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq == new_freq:
+        return w[0] if squeeze else w
+    g = math.gcd(orig_freq, new_freq)
+    orig, new = orig_freq // g, new_freq // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / orig)
+    length = w.shape[-1]
+    x = torch.nn.functional.pad(w, (width, width + orig))
+    y = torch.nn.functional.conv1d(x[:, None], kernels.float(), stride=orig)          # (channels, new, frames)
+    y = y.transpose(1, 2).reshape(w.shape[0], -1)
+    y = y[..., :math.ceil(new * length / orig)]
+    return y[0] if squeeze else y
+
+
+def convert_ts_float(input_string: str):
+    """'[(0.0, 0.1), (0.1, 0.25)]' -> [(0.0, 0.1), (0.1, 0.25)] (utility.py:298-309)."""
+    s = input_string.replace('[', '').replace(']', '').replace(' ', '')
+    out = []
+    for piece in s.split('),('):
+        a, b = map(float, piece.strip('()').split(','))
+        out.append((a, b))
+    return out
+
+
+def phonemes_idx(vocab: dict, phonemes: str) -> List[int]:
+    """Space-separated phoneme string -> vocabulary ids (utility.py:236-244)."""
+    return [vocab[p] for p in phonemes.split(' ')]
+
+
+def crop_one_second(audio, phoneme_timestamps: str, phonemes: str, vocab: dict, rng=None, duration_samples: int = 16000):
+    """The optional 1-second training crop of data/dataset_commonphone.py:35-70: a random window of `duration_samples` and the
+    ids of the phonemes that overlap it (first = the phoneme that contains the window start, last = the one that contains its
+    end).  `rng` needs `randint(a, b)` with both ends included (default: the `random` module, as the reference)."""
+    import random as _random
+    rng = rng or _random
+    audio = torch.as_tensor(audio)
+    start = rng.randint(0, len(audio) - duration_samples)
+    end = start + duration_samples
+    crop = audio[start:end]
+    t0, t1 = start / 16000, end / 16000
+    ts = convert_ts_float(phoneme_timestamps)
+    hit = []
+    for i, (a, b) in enumerate(ts):
+        if a <= t0 < b:
+            hit.append(i)
+        if a < t1 <= b:
+            hit.append(i)
+    assert len(hit) == 2
+    names = phonemes.split(' ')
+    label = phonemes_idx(vocab, ' '.join(names[i] for i in range(hit[0], hit[1] + 1)))
+    return {"audio": crop, "audio_len": len(crop), "phoneme_label": label}

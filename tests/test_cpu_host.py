@@ -194,3 +194,36 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
                        timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_resample_and_one_second_crop():
+    """Input pipeline (data/dataset_commonphone.py:17-86): sinc resampling to 16 kHz (torchaudio absent: parity unpinned, properties
+    pinned) and the 1-second crop with its phoneme labels."""
+    import math
+    import random
+    sr = 44100
+    tt = torch.arange(sr, dtype=torch.float64) / sr
+    tone = torch.sin(2 * math.pi * 440.0 * tt).float()
+    y = hostlogic.resample(tone, sr, 16000)
+    assert y.shape == (16000,) and y.dtype == torch.float32
+    want = torch.sin(2 * math.pi * 440.0 * torch.arange(16000, dtype=torch.float64) / 16000).float()
+    assert (y[200:-200] - want[200:-200]).abs().max().item() < 2e-3            # a tone keeps frequency, phase and amplitude
+    dc = hostlogic.resample(torch.ones(48000), 48000, 16000)
+    assert dc.shape == (16000,) and (dc[100:-100] - 1).abs().max().item() < 1e-3
+    assert torch.equal(hostlogic.resample(tone, 16000, 16000), tone)
+    assert hostlogic.resample(torch.randn(2, 22050), 22050).shape == (2, 16000)
+    hi = torch.sin(2 * math.pi * 12000.0 * tt).float()                           # above the new Nyquist: removed
+    assert hostlogic.resample(hi, sr, 16000)[200:-200].abs().max().item() < 2e-2
+    # crop
+    vocab = {"a": 1, "b": 2, "c": 3, "d": 4}
+    audio = torch.arange(40000, dtype=torch.float32)
+    ts = "[(0.0, 0.5), (0.5, 1.2), (1.2, 1.9), (1.9, 2.5)]"
+    random.seed(3)
+    item = hostlogic.crop_one_second(audio, ts, "a b c d", vocab)
+    s0 = int(item["audio"][0])
+    assert item["audio_len"] == 16000 and torch.equal(item["audio"], audio[s0:s0 + 16000])
+    t0, t1 = s0 / 16000, s0 / 16000 + 1.0
+    spans = hostlogic.convert_ts_float(ts)
+    first = [i for i, (a, b) in enumerate(spans) if a <= t0 < b][0]
+    last = [i for i, (a, b) in enumerate(spans) if a < t1 <= b][0]
+    assert item["phoneme_label"] == [1, 2, 3, 4][first:last + 1]

@@ -70,8 +70,8 @@ def test_force_aptai_large_30s_against_the_oracle_at_reduced_depth():
 
 def test_force_aptai_large_30s_full_depth_properties():
     """24 layers, 2 x 30 s: shapes, finite losses and head gradients, aligned ids drawn from each utterance's own phoneme list,
-    and utterance independence - the first utterance alone gives bit-identical trajectories and alignment (no cross-utterance
-    coupling anywhere on the path, padding included: the second utterance is shorter)."""
+    and utterance independence - the first utterance alone gives the same alignment and trajectories (no cross-utterance coupling
+    anywhere on the path, padding included: the second utterance is shorter)."""
     from oracle import synth
     model, pr_cfg, _ = _setup(24)
     model.eval()
@@ -89,8 +89,9 @@ def test_force_aptai_large_30s_full_depth_properties():
         assert set(int(v) for v in out["pred_frame_phns"][b]) <= set(int(v) for v in lists[b])
     n0 = len(out["pred_frame_phns"][0])
     assert out["pred_frame_phns"][0] == one["pred_frame_phns"][0]
-    # batch 1 runs its LSTM over all frames (models/modules.py:209-212); utterance 0 is full length, so the two agree exactly
-    assert n0 == 1499 and torch.equal(out["tvs_pred"][0], one["tvs_pred"][0])
+    # batch 1 runs its LSTM over all frames (models/modules.py:209-212); utterance 0 is full length, so the two runs compute the
+    # same thing - up to fp32 summation order: the fp32 head GEMMs pick their K split from the batch size
+    assert n0 == 1499 and (out["tvs_pred"][0] - one["tvs_pred"][0]).abs().max().item() < 1e-4
     model.train()
     out = model(0, **cb, _phn_pred_list=lists)
     out["loss"].backward()
