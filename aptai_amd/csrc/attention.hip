@@ -38,6 +38,7 @@ struct AttnArgs {
     float* delta;
     bf16_t* dqkv;
     int skip_pad_q;
+    int stagger;                    // experiment: s_sleep units (64 clocks) per wave-slot index at kernel start
 };
 
 // ---- LDS tile [rows][64] bf16, 128-B rows, 16-B chunk index XORed with tile_swz(row) = row bits (2, 3, 1) -> swizzle bits
@@ -86,6 +87,40 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 // accumulator register r of a 32x32 tile <-> row (r&3) + 8*(r>>2) + 4*h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// ---- coalesced block prologue / epilogue helpers (the per-BLOCK cost: a lane owns one ROW in these kernels, so direct
+// fragment loads / accumulator stores touch 32-64 cache lines per instruction)
+constexpr int OUT_PITCH = 144;                                  // bytes per staged row (128 + 16: odd number of 16-B units)
+constexpr int STAGE_BYTES = 4 * 32 * OUT_PITCH;                 // 18 432 B: 32 rows per wave
+
+// [128 rows][64] bf16 (row stride ld elements) -> LDS tile layout (tile_off), 8 lanes per 128-byte row
+__device__ __forceinline__ void stage_rows128(char* dst, const bf16_t* src, long ld, int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int cid = it * 256 + tid, row = cid >> 3, ch = cid & 7;
+        *(u32x4*)(dst + tile_off(row, ch)) = *(const u32x4*)(src + (long)row * ld + ch * 8);
+    }
+}
+// the wave's transposed accumulator pair acc[dt][4 g4 + j] = X^T[d = 32 dt + 8 g4 + 4 h + j][row = lane & 31], scaled, as bf16
+// rows of 128 bytes: through the wave's own staging area sw (32 x OUT_PITCH), then 16-byte chunks of whole rows
+__device__ __forceinline__ void store_rows_bf16(char* sw, const f32x16 (&acc)[2], float scale, bf16_t* g_row0, long ld, int lane) {
+    const int r31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = dt * 32 + 8 * g4 + 4 * h;
+            *(u32x2*)(sw + r31 * OUT_PITCH + d * 2) = (u32x2){pack2bf(acc[dt][4 * g4] * scale, acc[dt][4 * g4 + 1] * scale),
+                                                              pack2bf(acc[dt][4 * g4 + 2] * scale, acc[dt][4 * g4 + 3] * scale)};
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // same wave, LDS in order: only the compiler must not reorder
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 64 + lane, r = idx >> 3, ch = idx & 7;
+        *(u32x4*)(g_row0 + (long)r * ld + ch * 8) = *(const u32x4*)(sw + r * OUT_PITCH + ch * 16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // dropout on P: one hash per PAIR of consecutive keys of one query row; pair index = (bh*Tp + q)*(Tp/2) + key/2 (32-bit)
 __device__ __forceinline__ bool attn_keep(uint32_t pair, int key, uint32_t s0, uint32_t s1, uint32_t thr16) {
     const uint32_t hsh = rng_hash(pair, s0, s1);
@@ -94,11 +129,30 @@ __device__ __forceinline__ bool attn_keep(uint32_t pair, int key, uint32_t s0, u
 
 // ================================================================================== forward
 // grid (Tp/128, heads, B), 256 threads; wave w: queries q0 = qt*128 + w*32 .. +31
+// The per-BLOCK cost matters as much as the tile loop at T ~ 500 (8 key tiles): the epilogue goes through LDS so that every
+// store instruction writes whole 128-byte row segments (a lane owns one QUERY, so storing from the accumulators directly is
+// 8 or 16 bytes per lane at a row stride: 32-64 distinct lines per instruction, 32 instructions per wave).
+//
+// Tile loop.  rocprofv3 counters (profiles/r02_attn_pmc.json) show the SIMD time of a tile is the SUM of its matrix time
+// (32 cycles per MFMA) and its vector-issue time: co-resident waves run the same phases in lockstep, so nothing overlaps
+// unless the interleave is in each wave's own instruction stream (an MFMA holds the vector issue port for 8 of its 32
+// cycles; up to 24 cycles of VALU issue behind it are free).  Hence:
+//   * reference-point softmax: p = exp2(c s - ref) with a per-query reference that is the true maximum of the FIRST tile
+//     and afterwards only moves (by an exact power of two) when a tile's row sum exceeds 2^14.  No per-tile maximum, no
+//     O / l rescale, and - the point - no dependency of the exponentials on the whole tile: the softmax of keys 0..31 is
+//     issued between the MFMAs of keys 32..63, the softmax of keys 32..63 between the first O^T MFMAs;
+//   * all fragment reads of a phase are issued before its first MFMA, the two accumulator chains alternate;
+//   * 2-deep LDS ring, ONE barrier per tile.
+constexpr int FWD_BUF = 2 * 64 * 128;                           // one K tile + one V tile (64 keys each)
+constexpr int FWD_SMEM = 2 * FWD_BUF;                           // 2-deep ring, 32 KB (>= the 18 KB of epilogue staging)
+constexpr float REF_SUM_LIMIT = 16384.0f;
+
+template <bool V> struct Flag { static constexpr bool value = V; };
+
+template <bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];   // K tile, V tile (64 keys each)
-    char* sK = smem;
-    char* sV = smem + 64 * 128;
-    if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
+    __shared__ __attribute__((aligned(16))) char smem[FWD_SMEM];
+    if (DROP) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = blockIdx.z, hd = blockIdx.y;
     const int q0 = blockIdx.x * 128 + wave * 32;
@@ -115,11 +169,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     bf16x8 qf[4];
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(Qg + ds * 16 + h * 8);
+    // keep the Q loads OLDER than every K/V load: the wait for tile 0 then covers them, and the tile loop carries no
+    // vmcnt for them (the scheduler had moved two of them behind the tile loads: a vmcnt(1) inside the S chain, per tile)
+    __builtin_amdgcn_sched_barrier(0);
 
     f32x16 oT[2];
     oT[0] = (f32x16)(0.f);
     oT[1] = (f32x16)(0.f);
-    float m_run = -INFINITY, l_run = 0.f;      // running max in the RAW score domain, running sum in the exp2 domain
+    float ref = 0.f, l_run = 0.f;              // reference in the exp2 domain (c * raw score), running sum relative to it
 
     // staging: 512 16-B chunks per tile, 2 per thread per tensor; offsets are loop invariant
     int soff[2];
@@ -134,131 +191,204 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     const long tile_stride = 64 * a.ld;
 #pragma unroll
     for (int it = 0; it < 2; ++it) { kreg[it] = *(const u32x4*)(Kg + goff[it]); vreg[it] = *(const u32x4*)(Vg + goff[it]); }
-    const uint32_t pbase = (uint32_t)(((b * a.heads + hd) * a.Tp + q) * (a.Tp >> 1));
+    // dropout: row hash of this lane's query + (pair index) * K1; registers r, r+1 are the two keys of pair
+    // (kbase + 32 kt2 + acc_row(r, h)) / 2 = kbase / 2 + 2 h + 16 kt2 + acc_row(r, 0) / 2
+    uint32_t hbase = 0;
+    if (DROP) hbase = rng_hash((uint32_t)((b * a.heads + hd) * a.Tp + q), a.seed0, a.seed1) + (uint32_t)(2 * h) * ATTN_K1;
     const float c = a.c;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) { *(u32x4*)(smem + soff[it]) = kreg[it]; *(u32x4*)(smem + 64 * 128 + soff[it]) = vreg[it]; }
+    if (ntiles > 1) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            kreg[it] = *(const u32x4*)(Kg + tile_stride + goff[it]);
+            vreg[it] = *(const u32x4*)(Vg + tile_stride + goff[it]);
+        }
+    }
+    __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();
+    // one key tile; FIRST: take the reference from this tile's maximum; MASK: keys >= len are excluded (last tile only)
+    auto tile = [&](auto first_flag, auto mask_flag, const int t) {
+        constexpr bool FIRST = decltype(first_flag)::value, MASK = decltype(mask_flag)::value;
+        const char* sK = smem + (t & 1) * FWD_BUF;
+        const char* sV = sK + 64 * 128;
+        const int kbase = t * 64;
+        bf16x8 kfr[2][4];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) { *(u32x4*)(sK + soff[it]) = kreg[it]; *(u32x4*)(sV + soff[it]) = vreg[it]; }
-        __syncthreads();
+        for (int ds = 0; ds < 4; ++ds) kfr[0][ds] = rd_row(sK, lo, 0, ds);
         if (t + 1 < ntiles) {
-            const bf16_t* kn = Kg + (long)(t + 1) * tile_stride;
-            const bf16_t* vn = Vg + (long)(t + 1) * tile_stride;
+            char* nb = smem + ((t + 1) & 1) * FWD_BUF;
 #pragma unroll
-            for (int it = 0; it < 2; ++it) { kreg[it] = *(const u32x4*)(kn + goff[it]); vreg[it] = *(const u32x4*)(vn + goff[it]); }
+            for (int it = 0; it < 2; ++it) { *(u32x4*)(nb + soff[it]) = kreg[it]; *(u32x4*)(nb + 64 * 128 + soff[it]) = vreg[it]; }
+            if (t + 2 < ntiles) {
+                const bf16_t* kn = Kg + (long)(t + 2) * tile_stride;
+                const bf16_t* vn = Vg + (long)(t + 2) * tile_stride;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) { kreg[it] = *(const u32x4*)(kn + goff[it]); vreg[it] = *(const u32x4*)(vn + goff[it]); }
+            }
         }
         // S^T tiles: keys (kt2*32 + acc_row) x queries (lane&31)
         f32x16 sT[2];
+        sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][0], qf[0], (f32x16)(0.f), 0, 0, 0);
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2) {
-            sT[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sK, lo, kt2, 0), qf[0], (f32x16)(0.f), 0, 0, 0);
+        for (int ds = 1; ds < 4; ++ds) sT[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][ds], qf[ds], sT[0], 0, 0, 0);
 #pragma unroll
-            for (int ds = 1; ds < 4; ++ds)
-                sT[kt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sK, lo, kt2, ds), qf[ds], sT[kt2], 0, 0, 0);
-        }
-        const int kbase = t * 64;
-        if (kbase + 64 > len) {                               // boundary tile only: mask keys >= len (wave-uniform branch)
+        for (int ds = 0; ds < 4; ++ds) kfr[1][ds] = rd_row(sK, lo, 1, ds);
+        sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1][0], qf[0], (f32x16)(0.f), 0, 0, 0);
+#pragma unroll
+        for (int ds = 1; ds < 4; ++ds) sT[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1][ds], qf[ds], sT[1], 0, 0, 0);
+        if (MASK) {
 #pragma unroll
             for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kbase + kt2 * 32 + acc_row(r, h) >= len) sT[kt2][r] = -INFINITY;
         }
-        float mt = sT[0][0];
+        if (FIRST) {                                            // the tile holds at least one valid key: the maximum is finite
+            float mt = sT[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sT[0][r]);
+            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sT[0][r]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sT[1][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = fast_exp2((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
-        float x[2][16];
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sT[1][r]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            ref = mt * c;
+        }
         float psum = 0.f;
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2)
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+            // V^T fragments of this half's 32 keys: their LDS latency hides under the half's softmax arithmetic
+            bf16x8 vfr[2][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(fmaf(sT[kt2][r], c, -mc));
-                psum += p;
-                x[kt2][r] = p;
-            }
-        if (a.thr16) {
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int kt2 = 0; kt2 < 2; ++kt2)
+                for (int dt = 0; dt < 2; ++dt) vfr[s][dt] = rd_tr(sV, lo, 2 * kt2 + s, dt);
+            float x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[r] = fast_exp2(fmaf(sT[kt2][r], c, -ref)); psum += x[r]; }
+            if (DROP) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {              // registers r, r+1 are consecutive keys: one hash per pair
-                    const int key = kbase + kt2 * 32 + acc_row(r, h);
-                    const uint32_t hsh = rng_hash(pbase + (uint32_t)(key >> 1), a.seed0, a.seed1);
-                    x[kt2][r] = (hsh & 0xffffu) >= a.thr16 ? x[kt2][r] : 0.f;          // the 1/(1-p) factor rides on the
-                    x[kt2][r + 1] = (hsh >> 16) >= a.thr16 ? x[kt2][r + 1] : 0.f;      // final 1/l normalisation
+                    const uint32_t hsh = attn_mix(hbase + (uint32_t)(kbase / 2 + 16 * kt2 + acc_row(r, 0) / 2) * ATTN_K1);
+                    x[r] = (hsh & 0xffffu) >= a.thr16 ? x[r] : 0.f;                    // the 1/(1-p) factor rides on the
+                    x[r + 1] = (hsh >> 16) >= a.thr16 ? x[r + 1] : 0.f;                // final 1/l normalisation
                 }
+            }
+            const bf16x8 pf0 = pack8(&x[0]), pf1 = pack8(&x[8]);
+            // O^T += V^T P^T : 2 k-steps of 16 keys
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0][dt], pf0, oT[dt], 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[1][dt], pf1, oT[dt], 0, 0, 0);
         }
-        l_run = fmaf(l_run, alpha, psum);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run += psum;
+        // the reference moves only when a row sum says some p passed 2^14 / 64 (or overflowed): exact power-of-two rescale of
+        // O and l (this tile's products included), applied after the fact - rare, wave-uniform
+        if (!FIRST && __builtin_amdgcn_ballot_w64(!(psum <= REF_SUM_LIMIT))) {
+            if (!(psum <= REF_SUM_LIMIT)) {
+                // (an overflowed row - psum = inf - cannot be repaired in place; the 2^14 margin makes that a 2^114 jump
+                //  of one score over everything before it, outside what bf16 Q K^T with |s| < 2^17 can produce per tile... it is
+                //  still flagged: the lse becomes inf and the context row NaN instead of silently wrong.)
+                const float e = floorf(fast_log2(psum));
+                const float sc = fast_exp2(-e);
+                ref += e;
+                l_run *= sc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { oT[0][r] *= alpha; oT[1][r] *= alpha; }
-        // O^T += V^T P^T : 4 k-steps of 16 keys
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bf16x8 pf = pack8(&x[s >> 1][8 * (s & 1)]);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(sV, lo, s, dt), pf, oT[dt], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) { oT[0][r] *= sc; oT[1][r] *= sc; }
+            }
         }
+        __syncthreads();           // every wave has read buffer t&1 (its fragments are consumed); buffer (t+1)&1 is written
+    };
+    if (ntiles == 1) {
+        tile(Flag<true>{}, Flag<true>{}, 0);
+    } else {
+        tile(Flag<true>{}, Flag<false>{}, 0);
+        for (int t = 1; t + 1 < ntiles; ++t) tile(Flag<false>{}, Flag<false>{}, t);
+        tile(Flag<false>{}, Flag<true>{}, ntiles - 1);
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run;                 // both half-waves' keys are in (psum was exchanged per tile)
     const float inv = __frcp_rn(l_tot) * a.dscale;
-    bf16_t* og = a.ctx + (rowbase + q) * a.ldo + hd * HD;
+    if (a.lse2 && h == 0) a.lse2[((long)b * a.heads + hd) * a.Tp + q] = ref + fast_log2(l_tot);
+    // epilogue through LDS: [32 queries][OUT_PITCH] per wave, written 8 / 16 bytes per lane, read back as 16-byte chunks of
+    // whole rows so that 8 lanes cover one 128-byte line
+    char* sw = smem + wave * (32 * OUT_PITCH);                 // (the loop's last barrier released the K / V tiles)
+    const int r31 = lane & 31;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
+            oT[dt][4 * g4 + 0] *= inv; oT[dt][4 * g4 + 1] *= inv; oT[dt][4 * g4 + 2] *= inv; oT[dt][4 * g4 + 3] *= inv;
             const int d = dt * 32 + 8 * g4 + 4 * h;
-            const float o0 = oT[dt][4 * g4 + 0] * inv, o1 = oT[dt][4 * g4 + 1] * inv, o2 = oT[dt][4 * g4 + 2] * inv,
-                        o3 = oT[dt][4 * g4 + 3] * inv;
-            *(u32x2*)(og + d) = (u32x2){pack2bf(o0, o1), pack2bf(o2, o3)};
-            if (a.o32) *(f32x4*)(a.o32 + (rowbase + q) * a.ldo + hd * HD + d) = (f32x4){o0, o1, o2, o3};
+            *(u32x2*)(sw + r31 * OUT_PITCH + d * 2) = (u32x2){pack2bf(oT[dt][4 * g4], oT[dt][4 * g4 + 1]),
+                                                              pack2bf(oT[dt][4 * g4 + 2], oT[dt][4 * g4 + 3])};
         }
-    if (a.lse2 && h == 0) a.lse2[((long)b * a.heads + hd) * a.Tp + q] = fmaf(m_run, c, fast_log2(l_tot));
+    __syncthreads();
+    const long orow = (rowbase + q0) * a.ldo + hd * HD;         // first query of this wave
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 64 + lane, r = idx >> 3, ch = idx & 7;
+        *(u32x4*)(a.ctx + orow + (long)r * a.ldo + ch * 8) = *(const u32x4*)(sw + r * OUT_PITCH + ch * 16);
+    }
+    if (a.o32) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            __syncthreads();
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *(f32x4*)(sw + r31 * OUT_PITCH + (8 * g4 + 4 * h) * 4) =
+                    (f32x4){oT[dt][4 * g4], oT[dt][4 * g4 + 1], oT[dt][4 * g4 + 2], oT[dt][4 * g4 + 3]};
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = i * 64 + lane, r = idx >> 3, ch = idx & 7;
+                *(f32x4*)(a.o32 + orow + (long)r * a.ldo + dt * 32 + ch * 4) = *(const f32x4*)(sw + r * OUT_PITCH + ch * 16);
+            }
+        }
+    }
 }
 
 // ================================================================================== backward: dK, dV
 // grid (Tp/128, heads, B); wave w owns keys key0 = kt*128 + w*32 .. +31; loops over 32-query tiles.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * 128 + 256];   // Q tile, dO tile (32 queries each), lse|delta
+    __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES + 384];   // staging; Q tile, dO tile (32 queries each)
     char* sQ = smem;
     char* sD = smem + 32 * 128;
-    float* sL = (float*)(smem + 2 * 32 * 128);                             // [0,32) lse2, [32,64) delta of the tile's queries
+    float* sL = (float*)(smem + STAGE_BYTES);           // [0,32) lse2, [32,64) delta, [64,96) dropout row hash of the tile's queries
     if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = blockIdx.z, hd = blockIdx.y;
-    const int key0 = blockIdx.x * 128 + wave * 32;
+    const int kb0 = blockIdx.x * 128;
+    const int key0 = kb0 + wave * 32;
     int len = a.lens[b];
     len = len < 1 ? 1 : (len > a.Tp ? a.Tp : len);
     const long rowbase = (long)b * a.Tp;
     const int key = key0 + (lane & 31);
-    bf16_t* dKg = a.dqkv + (rowbase + key) * a.ld + a.H + hd * HD;
-    bf16_t* dVg = dKg + a.H;
-    if (blockIdx.x * 128 >= len) {          // whole block beyond the utterance: gradients are exactly zero
+    bf16_t* dK0 = a.dqkv + (rowbase + kb0) * a.ld + a.H + hd * HD;        // row kb0 of this block's dK / dV columns
+    bf16_t* dV0 = dK0 + a.H;
+    if (kb0 >= len) {                       // whole block beyond the utterance: gradients are exactly zero
         const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(u32x4*)(dKg + (h * 4 + i) * 8) = z;
-            *(u32x4*)(dVg + (h * 4 + i) * 8) = z;
+        for (int it = 0; it < 4; ++it) {
+            const int cid = it * 256 + tid, row = cid >> 3, ch = cid & 7;
+            *(u32x4*)(dK0 + (long)row * a.ld + ch * 8) = z;
+            *(u32x4*)(dV0 + (long)row * a.ld + ch * 8) = z;
         }
         return;
     }
     const LaneOffs lo = lane_offs(lane);
-    const bf16_t* Kg = a.qkv + (rowbase + key) * a.ld + a.H + hd * HD;
-    const bf16_t* Vg = Kg + a.H;
+    // K and V fragments of the block's 128 keys through LDS (whole 128-byte rows per 8 lanes)
     bf16x8 kf[4], vf[4];
+    const bf16_t* K0 = a.qkv + (rowbase + kb0) * a.ld + a.H + hd * HD;
+    stage_rows128(smem, K0, a.ld, tid);
+    __syncthreads();
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-        kf[ds] = *(const bf16x8*)(Kg + ds * 16 + h * 8);
-        vf[ds] = *(const bf16x8*)(Vg + ds * 16 + h * 8);
-    }
+    for (int ds = 0; ds < 4; ++ds) kf[ds] = rd_row(smem, lo, wave, ds);
+    __syncthreads();
+    stage_rows128(smem, K0 + a.H, a.ld, tid);
+    __syncthreads();
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) vf[ds] = rd_row(smem, lo, wave, ds);
+    // (the tile loop opens with a barrier before it overwrites the staging area)
     f32x16 dKT[2], dVT[2];
     dKT[0] = dKT[1] = dVT[0] = dVT[1] = (f32x16)(0.f);
 
@@ -280,18 +410,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const bool wave_boundary = key0 + 32 > len;
     const uint32_t hshift = (key & 1) ? 16u : 0u;
     const float c = a.c;
-    const uint32_t half = (uint32_t)(a.Tp >> 1);
-    const uint32_t pkey = (uint32_t)((b * a.heads + hd) * a.Tp) * half + (uint32_t)(key >> 1);   // + q*half per element
+    // dropout: the keys sit on the lanes here, so the row hashes of the tile's 32 queries (level 1 of the two-level hash)
+    // ride along with lse2 / delta: threads 32..63 compute one each for the NEXT tile while this one is consumed
+    const uint32_t pairk = (uint32_t)(key >> 1) * ATTN_K1;
+    const uint32_t rowid0 = (uint32_t)((b * a.heads + hd) * a.Tp) + (uint32_t)(tid & 31);
+    uint32_t hreg = 0;
+    if (a.thr16 && tid >= 32 && tid < 64) hreg = rng_hash(rowid0, a.seed0, a.seed1);
     for (int t = 0; t < nq; ++t) {
         __syncthreads();
         *(u32x4*)(sQ + soff) = qreg;
         *(u32x4*)(sD + soff) = dreg;
         if (tid < 16) *(f32x4*)(sL + tid * 4) = sreg;
+        if (a.thr16 && tid >= 32 && tid < 64) ((uint32_t*)sL)[64 + (tid & 31)] = hreg;
         __syncthreads();
         if (t + 1 < nq) {
             qreg = *(const u32x4*)(Qb + (long)(t + 1) * 32 * a.ld + gq);
             dreg = *(const u32x4*)(Db + (long)(t + 1) * 32 * a.ldo + gd);
             if (tid < 16) sreg = *(const f32x4*)(stat + (t + 1) * 32);
+            if (a.thr16 && tid >= 32 && tid < 64) hreg = rng_hash(rowid0 + (uint32_t)((t + 1) * 32), a.seed0, a.seed1);
         }
         // S[q][key] and dP[q][key]
         f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sQ, lo, 0, 0), kf[0], (f32x16)(0.f), 0, 0, 0);
@@ -317,21 +453,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) pd[r] = key_ok ? pd[r] : 0.f;
         }
         if (a.thr16) {
-            // the pair (keys 2k, 2k+1) of one query shares a hash and sits on lanes l, l^1: the even lane hashes the even
-            // register's query, the odd lane the odd register's, and one DPP quad-permute hands each its partner's value
+            // element (query = register, key = lane): level-2 mix of the query's row hash with this lane's pair index; the
+            // lane's key parity picks the half (bfe)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const uint32_t mine = rng_hash(pkey + (uint32_t)(t * 32 + acc_row(r, h) + (lane & 1)) * half, a.seed0, a.seed1);
-                const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xf, 0xf, false);
-                const uint32_t h0 = (lane & 1) ? other : mine, h1 = (lane & 1) ? mine : other;
-                const bool k0 = ((h0 >> hshift) & 0xffffu) >= a.thr16, k1 = ((h1 >> hshift) & 0xffffu) >= a.thr16;
-                const float p0 = pd[r], p1 = pd[r + 1];
-                // dS = dscale * P (keep * dP - delta / dscale), P_drop = dscale * keep * P: the dQ kernel left delta / dscale in
-                // a.delta and the 1/(1-p) factors are applied once to dK and dV in the epilogue
-                dsv[r] = p0 * ((k0 ? dp[r] : 0.f) - dsv[r]);
-                dsv[r + 1] = p1 * ((k1 ? dp[r + 1] : 0.f) - dsv[r + 1]);
-                pd[r] = k0 ? p0 : 0.f;
-                pd[r + 1] = k1 ? p1 : 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const u32x4 rh = *(const u32x4*)((const uint32_t*)sL + 64 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = 4 * g4 + rr;
+                    const uint32_t y = attn_mix(rh[rr] + pairk);
+                    const bool k = ((y >> hshift) & 0xffffu) >= a.thr16;
+                    const float p0 = pd[r];
+                    // dS = dscale * P (keep * dP - delta / dscale), P_drop = dscale * keep * P: the dQ kernel left delta / dscale
+                    // in a.delta and the 1/(1-p) factors are applied once to dK and dV in the epilogue
+                    dsv[r] = p0 * ((k ? dp[r] : 0.f) - dsv[r]);
+                    pd[r] = k ? p0 : 0.f;
+                }
             }
         } else {
 #pragma unroll
@@ -348,63 +485,70 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
             }
         }
     }
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int d = dt * 32 + 8 * g4 + 4 * h;
-            const float ks = a.scale * a.dscale, vs = a.dscale;
-            *(u32x2*)(dKg + d) = (u32x2){pack2bf(dKT[dt][4 * g4] * ks, dKT[dt][4 * g4 + 1] * ks),
-                                         pack2bf(dKT[dt][4 * g4 + 2] * ks, dKT[dt][4 * g4 + 3] * ks)};
-            *(u32x2*)(dVg + d) = (u32x2){pack2bf(dVT[dt][4 * g4] * vs, dVT[dt][4 * g4 + 1] * vs),
-                                         pack2bf(dVT[dt][4 * g4 + 2] * vs, dVT[dt][4 * g4 + 3] * vs)};
-        }
+    __syncthreads();                                           // the Q / dO tiles become the epilogue staging area
+    char* sw = smem + wave * (32 * OUT_PITCH);
+    store_rows_bf16(sw, dKT, a.scale * a.dscale, dK0 + (long)(wave * 32) * a.ld, a.ld, lane);
+    store_rows_bf16(sw, dVT, a.dscale, dV0 + (long)(wave * 32) * a.ld, a.ld, lane);
 }
 
 // ================================================================================== backward: dQ
 // grid (Tp/128, heads, B); wave w owns queries q0 = qt*128 + w*32 .. +31; loops over 32-key tiles.
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * 128];   // K tile, V tile (32 keys each)
+    __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES + 512];   // prologue / epilogue staging; K, V tiles (32 keys)
     char* sK = smem;
     char* sV = smem + 32 * 128;
+    float* sDel = (float*)(smem + STAGE_BYTES);                             // delta of the block's 128 queries
     if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int b = blockIdx.z, hd = blockIdx.y;
-    const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int qb0 = blockIdx.x * 128;
+    const int q = qb0 + wave * 32 + (lane & 31);
     int len = a.lens[b];
     len = len < 1 ? 1 : (len > a.Tp ? a.Tp : len);
     const long rowbase = (long)b * a.Tp;
-    const bf16_t* Qg = a.qkv + (rowbase + q) * a.ld + hd * HD;
-    const bf16_t* Dg = a.dctx + (rowbase + q) * a.ldo + hd * HD;
     const LaneOffs lo = lane_offs(lane);
+    // Q and dO fragments through LDS (whole 128-byte rows per 8 lanes), one tensor at a time through the same 16 KB
     bf16x8 qf[4], df[4];
+    stage_rows128(smem, a.qkv + (rowbase + qb0) * a.ld + hd * HD, a.ld, tid);
+    __syncthreads();
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-        qf[ds] = *(const bf16x8*)(Qg + ds * 16 + h * 8);
-        df[ds] = *(const bf16x8*)(Dg + ds * 16 + h * 8);
-    }
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = rd_row(smem, lo, wave, ds);
+    __syncthreads();
+    stage_rows128(smem, a.dctx + (rowbase + qb0) * a.ldo + hd * HD, a.ldo, tid);
     const float lse_q = a.lse2[((long)b * a.heads + hd) * a.Tp + q];
-    // delta = rowsum(dO * O) of this lane's query: each half-wave lane holds 32 of the 64 head dims (the dO fragments it
-    // feeds the MFMAs with); the fp32 context keeps it accurate.  Written once for the dK/dV kernel, which is launched after.
-    float del_q = 0.f;
-    if (a.o32) {
-        const float* Og = a.o32 + (rowbase + q) * a.ldo + hd * HD;
+    // delta = rowsum(dO * O) of the block's queries, 16 lanes per row (the fp32 context keeps it accurate): every load
+    // instruction covers 4 whole rows.  Written once for the dK/dV kernel, which is launched after.
+    {
+        const int part = lane & 15, rsub = lane >> 4;
 #pragma unroll
-        for (int ds = 0; ds < 4; ++ds) {
-            const f32x4 o0 = *(const f32x4*)(Og + ds * 16 + h * 8), o1 = *(const f32x4*)(Og + ds * 16 + h * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) del_q = fmaf((float)df[ds][j], o0[j], fmaf((float)df[ds][j + 4], o1[j], del_q));
-        }
-    } else {
-        const bf16_t* Og = a.ctx + (rowbase + q) * a.ldo + hd * HD;
-#pragma unroll
-        for (int ds = 0; ds < 4; ++ds) {
-            const bf16x8 o = *(const bf16x8*)(Og + ds * 16 + h * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) del_q = fmaf((float)df[ds][j], (float)o[j], del_q);
+        for (int it = 0; it < 8; ++it) {
+            const int row = wave * 32 + it * 4 + rsub;
+            const long g = (rowbase + qb0 + row) * a.ldo + hd * HD + part * 4;
+            const u32x2 dv = *(const u32x2*)(a.dctx + g);
+            float o[4];
+            if (a.o32) {
+                const f32x4 ov = *(const f32x4*)(a.o32 + g);
+                o[0] = ov[0]; o[1] = ov[1]; o[2] = ov[2]; o[3] = ov[3];
+            } else {
+                const u32x2 ov = *(const u32x2*)(a.ctx + g);
+                o[0] = lo_bf(ov[0]); o[1] = hi_bf(ov[0]); o[2] = lo_bf(ov[1]); o[3] = hi_bf(ov[1]);
+            }
+            float acc = lo_bf(dv[0]) * o[0];
+            acc = fmaf(hi_bf(dv[0]), o[1], acc);
+            acc = fmaf(lo_bf(dv[1]), o[2], acc);
+            acc = fmaf(hi_bf(dv[1]), o[3], acc);
+            acc += __shfl_xor(acc, 8, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 1, 64);
+            if (part == 0) sDel[row] = acc;
         }
     }
-    del_q += __shfl_xor(del_q, 32, 64);
+    __syncthreads();
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) df[ds] = rd_row(smem, lo, wave, ds);
+    float del_q = sDel[wave * 32 + (lane & 31)];
+    __syncthreads();                                           // the staging area becomes the K / V tiles
     // with attention dropout dS = dscale * P (keep * dP - delta / dscale): both backward kernels work with delta / dscale and
     // apply dscale = 1/(1-p) once in their epilogues (dscale = 1 without dropout)
     del_q *= __frcp_rn(a.dscale);
@@ -418,7 +562,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
     const int soff = tile_off(srow, sch);
     const long gk = (long)srow * a.ld + sch * 8;
     u32x4 kreg = *(const u32x4*)(Kb + gk), vreg = *(const u32x4*)(Vb + gk);
-    const uint32_t pbase = (uint32_t)(((b * a.heads + hd) * a.Tp + q) * (a.Tp >> 1));
+    uint32_t hbase = 0;                      // dropout: row hash of this lane's query + 2 h K1 (see the forward kernel)
+    if (a.thr16) hbase = rng_hash((uint32_t)((b * a.heads + hd) * a.Tp + q), a.seed0, a.seed1) + (uint32_t)(2 * h) * ATTN_K1;
     const float c = a.c;
     for (int t = 0; t < nk; ++t) {
         __syncthreads();
@@ -447,8 +592,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
         if (a.thr16) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const int key = t * 32 + acc_row(r, h);
-                const uint32_t hsh = rng_hash(pbase + (uint32_t)(key >> 1), a.seed0, a.seed1);
+                const uint32_t hsh = attn_mix(hbase + (uint32_t)(t * 16 + acc_row(r, 0) / 2) * ATTN_K1);
                 dpT[r] = (hsh & 0xffffu) >= a.thr16 ? dpT[r] : 0.f;
                 dpT[r + 1] = (hsh >> 16) >= a.thr16 ? dpT[r + 1] : 0.f;
             }
@@ -463,16 +607,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
                 dQT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_tr(sK, lo, sstep, dt), dsf, dQT[dt], 0, 0, 0);
         }
     }
-    bf16_t* dQg = a.dqkv + (rowbase + q) * a.ld + hd * HD;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int d = dt * 32 + 8 * g4 + 4 * h;
-            const float qs = a.scale * a.dscale;
-            *(u32x2*)(dQg + d) = (u32x2){pack2bf(dQT[dt][4 * g4] * qs, dQT[dt][4 * g4 + 1] * qs),
-                                         pack2bf(dQT[dt][4 * g4 + 2] * qs, dQT[dt][4 * g4 + 3] * qs)};
-        }
+    __syncthreads();                                           // the K / V tiles become the epilogue staging area
+    store_rows_bf16(smem + wave * (32 * OUT_PITCH), dQT, a.scale * a.dscale,
+                    a.dqkv + (rowbase + qb0 + wave * 32) * a.ld + hd * HD, a.ld, lane);
 }
 
 int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens, int64_t B, int64_t Tp, int64_t H,
@@ -487,6 +624,8 @@ int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens
     a.thr16 = drop_thr16(dropout_p); a.dscale = drop_scale(a.thr16);
     a.seed0 = (uint32_t)seed; a.seed1 = (uint32_t)(seed >> 32);
     a.salt = aptai_seed_salt(stream);
+    static const int stagger = getenv("APTAI_ATTN_STAGGER") ? atoi(getenv("APTAI_ATTN_STAGGER")) : 0;
+    a.stagger = stagger;
     return APTAI_OK;
 }
 
@@ -500,8 +639,13 @@ extern "C" int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* c
     if (rc) return rc;
     APTAI_REQUIRE(ctx != nullptr, "aptai_attention_fwd: null ctx");
     a.ctx = (bf16_t*)ctx; a.lse2 = lse2; a.o32 = ctx_f32;
-    APTAI_LAUNCH(attn_fwd_kernel, dim3((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B), dim3(256), 0,
-                       (hipStream_t)stream_, a);
+    if (a.thr16) {
+        APTAI_LAUNCH(attn_fwd_kernel<true>, dim3((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream_, a);
+    } else {
+        APTAI_LAUNCH(attn_fwd_kernel<false>, dim3((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream_, a);
+    }
     APTAI_CHECK_LAUNCH("attn_fwd_kernel");
     return APTAI_OK;
 }

@@ -183,22 +183,45 @@ __global__ void conv0_moments_final_kernel(const float* __restrict__ partials, c
 }
 
 // ---- mode 0 pass 2: conv -> (v - mean) * rstd * gamma + beta -> GELU.  grid (blocks, B)
+// VALU-bound, not HBM-bound: per output 10 conv FMAs + the affine + ~15 for GELU (two quarter-rate transcendentals) is
+// ~28 issue slots against 2 bytes written, i.e. ~0.19 ms of VALU time at 16 x 10 s against 85 us of HBM time.  So the
+// normalisation is folded into the taps once per block (w' = w * rstd * gamma, b' = (b - mean) * rstd * gamma + beta)
+// and the arithmetic runs on the packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two channels per issue slot).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -7.0f, 7.0f), __builtin_amdgcn_fmed3f(x.y, -7.0f, 7.0f)};
+    const f32x2 x2 = xc * xc;
+    f32x2 p = __builtin_elementwise_fma(x2, (f32x2){APTAI_GELU_A5 * APTAI_NLOG2E, APTAI_GELU_A5 * APTAI_NLOG2E},
+                                        (f32x2){APTAI_GELU_A3 * APTAI_NLOG2E, APTAI_GELU_A3 * APTAI_NLOG2E});
+    p = __builtin_elementwise_fma(p, x2, (f32x2){APTAI_GELU_A1 * APTAI_NLOG2E, APTAI_GELU_A1 * APTAI_NLOG2E});
+    const f32x2 z = xc * p;
+    const f32x2 e = (f32x2){__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + (f32x2){1.0f, 1.0f};
+    return x * (f32x2){__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+}
+
 __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    float w[8][KW], bias[8], sc[8], sh[8];
-    load_weights(a, lane, w, bias);
+    f32x2 w2[4][KW], b2[4];
+    {
+        float w[8][KW], bias[8];
+        load_weights(a, lane, w, bias);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = lane * 8 + j;
-        const float mu = a.stats[((long)b * 2 + 0) * C0 + c], rs = a.stats[((long)b * 2 + 1) * C0 + c];
-        sc[j] = rs * a.gamma[c];
-        sh[j] = a.beta[c] - mu * sc[j];
+        for (int j = 0; j < 8; ++j) {
+            const int c = lane * 8 + j;
+            const float mu = a.stats[((long)b * 2 + 0) * C0 + c], rs = a.stats[((long)b * 2 + 1) * C0 + c];
+            const float sc = rs * a.gamma[c];
+            const float sh = fmaf(bias[j] - mu, sc, a.beta[c]);
+#pragma unroll
+            for (int k = 0; k < KW; ++k) w2[j >> 1][k][j & 1] = w[j][k] * sc;
+            b2[j >> 1][j & 1] = sh;
+        }
     }
     const float* xb = a.audio + (long)b * a.S;
     bf16_t* ob = a.out + (long)b * a.T_alloc * C0;
     // the 10 samples of the NEXT frame are loaded before the current one is computed: without the prefetch every frame
-    // exposes one global-load latency to its wave (the loop body is only ~170 VALU instructions)
+    // exposes one global-load latency to its wave
     const int tstep = gridDim.x * 4;
     int t = blockIdx.x * 4 + wave;
     float xs[KW];
@@ -218,11 +241,12 @@ __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args a) {
         float o[8];
         if (t < a.T_real) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float acc = bias[j];
+            for (int j = 0; j < 4; ++j) {
+                f32x2 acc = b2[j];
 #pragma unroll
-                for (int k = 0; k < KW; ++k) acc = fmaf(xs[k], w[j][k], acc);
-                o[j] = gelu_fast(fmaf(acc, sc[j], sh[j]));
+                for (int k = 0; k < KW; ++k) acc = __builtin_elementwise_fma((f32x2){xs[k], xs[k]}, w2[j][k], acc);
+                const f32x2 g = gelu_fast2(acc);
+                o[2 * j] = g.x; o[2 * j + 1] = g.y;
             }
         } else {
 #pragma unroll

@@ -106,8 +106,9 @@ def test_pr_forward_against_reference_golden(name):
             got_n = named[n].grad.double().norm().item()
             ref_n = float(z[key])
             # q/k projections see the softmax Jacobian P*(dP - delta): a small difference of bf16-rounded terms, so
-            # with random weights their (tiny) gradients carry the most bf16 noise -> wider band for those two
-            tol = 0.25 if ("q_proj" in n or "k_proj" in n) else 6e-2
+            # with random weights their (tiny) gradients carry the most bf16 noise -> wider band for those two.
+            # Measured on MI355X (printed below): q/k <= 0.020, all others <= 0.0045; the bands are 3-4x that.
+            tol = 0.06 if ("q_proj" in n or "k_proj" in n) else 2e-2
             worst["qk" if ("q_proj" in n or "k_proj" in n) else "other"] = max(worst["qk" if ("q_proj" in n or "k_proj" in n) else "other"],
                                                                                abs(got_n - ref_n) / (ref_n + 1e-30))
             if abs(got_n - ref_n) > tol * ref_n + 1e-9:
@@ -123,7 +124,7 @@ def test_pr_forward_against_reference_golden(name):
             got_s, ref_s = flat[::step][:512].numpy(), z[key]
             rel = np.linalg.norm(got_s - ref_s) / (np.linalg.norm(ref_s) + 1e-30)
             print(f"[bands] {name}: slice rel-L2 {n}: {rel:.4f}")
-            assert rel < (0.3 if ("q_proj" in n or "k_proj" in n) else 0.12), (n, rel)
+            assert rel < 0.08, (n, rel)                 # measured <= 0.030 (layer-11 output_dense at 2 x 4 s)
     # eval helpers run and agree with the training logits (no dropout in the fixture)
     emb = model.get_embeddings(batch["input_values"], batch["input_lengths"])
     assert emb["last_transf_hidden"].shape[1] == cfg.hidden_size

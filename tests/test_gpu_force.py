@@ -208,7 +208,9 @@ def test_force_aptai_golden_b1():
             # is a noise band around the reference; the exact pin is test_force_aptai_b2_against_oracle (fp32 encoder output
             # fed to the same head kernels: 2e-3)
             print(f"[bands] force b1 gradient norm {n}: deviation {abs(got - ref) / (ref + 1e-30):.4f}")
-            if abs(got - ref) > 0.2 * ref + 1e-7:
+            # Measured: phn_emb_layer 0.082, xatt / frame_lin <= 0.015, everything behind the LSTM <= 0.004.
+            band = 0.2 if n.startswith("phn_emb_layer") else 0.05 if n.startswith(("xatt", "frame_lin")) else 0.015
+            if abs(got - ref) > band * ref + 1e-7:
                 bad.append((n, got, ref))
     assert not bad, bad
     assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("w2v2_pr."))

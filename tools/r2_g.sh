@@ -12,3 +12,5 @@ for prec in bf16 mxfp8; do
 done
 timeout -k 10 300 python bench.py --workload pr --steps 10 --warmup 3 --no-cpu-baseline > "$O/pr.json" 2> "$O/pr.err" || { tail -30 "$O/pr.err"; exit 1; }
 cut -c1-260 "$O/pr.json"
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$O/aptai.json" 2> "$O/aptai.err" || { tail -30 "$O/aptai.err"; exit 1; }
+cut -c1-260 "$O/aptai.json"
