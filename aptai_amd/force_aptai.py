@@ -173,30 +173,69 @@ class Force_APTAI(nn.Module):
         self.tv_lowpass = LowPassFilterLayer(self.device, 10, 49, 9)
         for param in self.w2v2_pr.parameters():
             param.requires_grad = False
+        self._enc_stream = None        # side stream of prefetch()
+        self._prefetched = None
 
     # ------------------------------------------------------------------ shared body
-    def _run(self, audio_inputs, audio_lengths, tv_targets=None, phn_pred_list=None, _ac_override=None):
-        """Encoder (inference) -> decode -> heads.  Nothing in here synchronises host and device: the best-path decode, the
-        phoneme slots, every length vector and the alignment read-out stay on the device; `_lists` makes the Python lists the
-        reference returns with one round of transfers at the very end."""
+    def _encode(self, audio_inputs, audio_lengths, phn_pred_list=None):
+        """Frozen recogniser (inference) + device best-path decode on the CURRENT stream: everything the heads read from it."""
         pr = self.w2v2_pr
         pr.eval()                                                      # models/w2v2_pr.py:125: the recogniser always runs in eval mode
         with torch.no_grad():
             lens1d = audio_lengths.reshape(-1)
             out, _ = pr._logits_eval(audio_inputs, lens1d[:, None])
-        g = out._geom
-        dev = out._flat_last.device
-        ac = out._flat_last if _ac_override is None else _ac_override      # test hook: heads on given embeddings
-        frame_lens = pr.wav2vec2._get_feat_extract_output_lengths(lens1d.to(dev)).to(torch.int32).contiguous()
-        if phn_pred_list is None:
-            ids, nlen = pr._decode_device(out, self.max_phn_seq_len)      # int32 [B][60] zero-padded, int32 [B]
-        else:
-            padded = []
-            for lst in phn_pred_list:
-                assert len(lst) < self.max_phn_seq_len, 'Need longer max phoneme sequence length.'
-                padded.append(np.pad(np.asarray(lst, dtype=np.int64), (0, self.max_phn_seq_len - len(lst)), mode='constant'))
-            ids = torch.tensor(np.array(padded), dtype=torch.int32, device=dev)
-            nlen = torch.tensor([len(l) for l in phn_pred_list], dtype=torch.int32, device=dev)
+            dev = out._flat_last.device
+            frame_lens = pr.wav2vec2._get_feat_extract_output_lengths(lens1d.to(dev)).to(torch.int32).contiguous()
+            if phn_pred_list is None:
+                ids, nlen = pr._decode_device(out, self.max_phn_seq_len)      # int32 [B][60] zero-padded, int32 [B]
+            else:
+                padded = []
+                for lst in phn_pred_list:
+                    assert len(lst) < self.max_phn_seq_len, 'Need longer max phoneme sequence length.'
+                    padded.append(np.pad(np.asarray(lst, dtype=np.int64), (0, self.max_phn_seq_len - len(lst)), mode='constant'))
+                ids = torch.tensor(np.array(padded), dtype=torch.int32, device=dev)
+                nlen = torch.tensor([len(l) for l in phn_pred_list], dtype=torch.int32, device=dev)
+        return SimpleNamespace(g=out._geom, ac=out._flat_last, ids=ids, nlen=nlen, frame_lens=frame_lens, step=pr.wav2vec2._step)
+
+    def prefetch(self, audio_inputs, audio_lengths):
+        """Run the frozen recogniser for a batch on a side stream NOW; the next forward / _run called with these same tensors
+        picks the result up instead of encoding inline.  The recogniser is frozen and runs in eval mode, so WHEN it runs does
+        not change any result; running it for batch n+1 beside the heads of batch n fills the CUs the cooperating LSTM
+        kernels (32 workgroups for 3.5 ms) leave idle.  Each step still does one encoder pass and one heads pass."""
+        if self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream(device=audio_inputs.device)
+        cur = torch.cuda.current_stream(audio_inputs.device)
+        self._enc_stream.wait_stream(cur)                              # the inputs (and the previous step's frees) are ordered first
+        with torch.cuda.stream(self._enc_stream):
+            enc = self._encode(audio_inputs, audio_lengths)
+            enc.event = torch.cuda.Event()
+            enc.event.record(self._enc_stream)
+        self._prefetched = (audio_inputs, audio_lengths, enc)
+
+    def _take_prefetched(self, audio_inputs, audio_lengths):
+        pf, self._prefetched = self._prefetched, None
+        if pf is None or pf[0] is not audio_inputs or pf[1] is not audio_lengths:
+            return None
+        enc = pf[2]
+        cur = torch.cuda.current_stream(audio_inputs.device)
+        cur.wait_event(enc.event)
+        for t in (enc.ac, enc.ids, enc.nlen, enc.frame_lens):         # allocated on the side stream, consumed on this one
+            t.record_stream(cur)
+        return enc
+
+    def _run(self, audio_inputs, audio_lengths, tv_targets=None, phn_pred_list=None, _ac_override=None, _prefetch_next=None):
+        """Encoder (inference) -> decode -> heads.  Nothing in here synchronises host and device: the best-path decode, the
+        phoneme slots, every length vector and the alignment read-out stay on the device; `_lists` makes the Python lists the
+        reference returns with one round of transfers at the very end."""
+        pr = self.w2v2_pr
+        enc = self._take_prefetched(audio_inputs, audio_lengths) if phn_pred_list is None else None
+        if enc is None:
+            enc = self._encode(audio_inputs, audio_lengths, phn_pred_list)
+        if _prefetch_next is not None:                                 # the NEXT batch's encoder pass goes out before this batch's heads
+            self.prefetch(*_prefetch_next)
+        g, ids, nlen, frame_lens = enc.g, enc.ids, enc.nlen, enc.frame_lens
+        dev = enc.ac.device
+        ac = enc.ac if _ac_override is None else _ac_override          # test hook: heads on given embeddings
         tr = self.training
         n_tv = self.rnn.linear[3].weight.shape[0]
         if tv_targets is None:
@@ -206,7 +245,7 @@ class Force_APTAI(nn.Module):
         rnn_lens = consts["full_T"](g.T) if g.B == 1 else frame_lens
         st = SimpleNamespace(g=g, ids=ids, pe=self.pe_phn.pe.reshape(_NPHN, -1).contiguous(), taps=self.tv_lowpass.taps(),
                              p_hid=self.hidden_drop if tr else 0.0, p_rnn=self.rnn_drop if tr else 0.0,
-                             seed=_seed(pr.wav2vec2.base_seed, pr.wav2vec2._step, 4242),
+                             seed=_seed(pr.wav2vec2.base_seed, enc.step, 4242),
                              tv_tgt=tv_targets.contiguous(), fs_targets=consts["fs_targets"], frame_lens=frame_lens, rnn_lens=rnn_lens,
                              text_lens=nlen, vocab_sizes=nlen + 1)
         if getattr(self, "dp_loss_norm", None) is not None and tr:
@@ -254,9 +293,11 @@ class Force_APTAI(nn.Module):
         return given, fl, n, table
 
     def forward(self, epoch, audio_inputs, audio_lengths, phoneme_labels, phn_frames_49hz, LA, LP, JA, TTCL, TTCD, TMCL, TMCD,
-                TBCL, TBCD, _phn_pred_list=None, _ac_override=None):
+                TBCL, TBCD, _phn_pred_list=None, _ac_override=None, _prefetch_next=None):
+        """`_prefetch_next = (audio_inputs, audio_lengths)` of the batch the NEXT call will receive (the same tensor objects)
+        starts its frozen-encoder pass on a side stream beside this call's heads (see prefetch)."""
         tv_targets = torch.stack([LA, LP, JA, TTCL, TTCD, TMCL, TMCD, TBCL, TBCD], dim=-1).float()
-        res, g, dec = self._run(audio_inputs, audio_lengths, tv_targets, _phn_pred_list, _ac_override)
+        res, g, dec = self._run(audio_inputs, audio_lengths, tv_targets, _phn_pred_list, _ac_override, _prefetch_next)
         loss, tv_loss, align_loss, tvs, frame_phns = res[:5]
         phn_pred_list, frame_seq_lens, _, _ = self._lists(dec)
         fp = frame_phns.cpu().numpy()                                  # ONE transfer (reference: B*T .cpu() calls)

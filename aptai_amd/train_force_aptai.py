@@ -64,10 +64,22 @@ def train(cfg, model, optimizer, lr_scheduler, train_dataloader, valid_dataloade
     for epoch in range(cfg.num_epochs):
         sum_train_loss, steps = 0.0, 0
         model.train()
-        for batch_idx, batch_x in enumerate(train_dataloader):
-            batch_x = {k: v.to(cfg.device) for k, v in batch_x.items()}
+        # one batch of lookahead: the frozen recogniser's pass for batch i+1 is started on a side stream before the heads of
+        # batch i are launched (Force_APTAI.prefetch; results do not depend on it).  cfg.pipeline_encoder = False turns it off.
+        pipelined = bool(getattr(cfg, "pipeline_encoder", True)) and str(cfg.device).startswith("cuda")
+        it = iter(train_dataloader)
+        nxt = next(it, None)
+        if nxt is not None:
+            nxt = {k: v.to(cfg.device) for k, v in nxt.items()}
+        batch_idx = -1
+        while nxt is not None:
+            batch_idx += 1
+            batch_x, nxt = nxt, next(it, None)
+            if nxt is not None:
+                nxt = {k: v.to(cfg.device) for k, v in nxt.items()}
             optimizer.zero_grad()
-            outputs = model(epoch, **batch_x)
+            ahead = (nxt["audio_inputs"], nxt["audio_lengths"]) if (pipelined and nxt is not None) else None
+            outputs = model(epoch, **batch_x, _prefetch_next=ahead)
             outputs["loss"].backward()
             optimizer.step()
             sum_train_loss += float(outputs["loss"].detach())

@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="aptai", choices=["aptai", "force", "pr"])
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="force workload: run the frozen encoder inline instead of one batch ahead on a side stream")
     ap.add_argument("--model", default="base", choices=["base", "large"])
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 16 base / 8 large)")
     ap.add_argument("--seconds", type=float, default=10.0)
@@ -378,6 +380,11 @@ def main():
         data_note += (f"; blank bias of the random-init recogniser raised by {bias:.3f} so that the best-path decode inside the "
                       f"step yields {min(counts)}..{max(counts)} phonemes per clip (a trained recogniser's regime)")
         call = lambda: model(0, **batch)
+        if not args.no_pipeline:
+            # every step: heads of this batch + the frozen-encoder pass of the next one on a side stream (Force_APTAI.prefetch);
+            # the first call encodes inline, so each timed step still holds exactly one encoder pass and one heads pass
+            nxt = (batch["audio_inputs"], batch["audio_lengths"])
+            call = lambda: model(0, **batch, _prefetch_next=nxt)
     w2v2.base_seed += rank
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]

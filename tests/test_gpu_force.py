@@ -305,3 +305,67 @@ def test_force_aptai_config3_size_step():
     heads = [(n, p) for n, p in model.named_parameters() if not n.startswith("w2v2_pr.") and p.requires_grad]
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in heads), [n for n, p in heads if p.grad is None]
     assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("w2v2_pr."))
+
+
+def test_force_aptai_prefetched_encoder_is_bit_identical_to_inline():
+    """Force_APTAI.prefetch: the frozen recogniser of batch i+1 on a side stream beside the heads of batch i.  Three training
+    steps over two alternating batches, once inline and once pipelined, from the same initial state: every loss, every TV
+    prediction and every head gradient must be EQUAL (the same kernels on the same inputs, only issued earlier), and a
+    prefetch for tensors that are not the ones passed next must be ignored."""
+    from oracle import synth
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.optim import Adam
+    z, meta = load_golden("force_aptai_1x2s")
+    pr_cfg = W2V2Config.from_any(meta["pr_cfg"])
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, meta["vocab_len"]), meta["seed"])
+    B, S = 4, 48000
+    batches = []
+    for seed in (8, 9):
+        bt = {k: v.cuda() for k, v in synth.synth_aptai_batch(pr_cfg, B, S, seed=seed, n_phn=40).items()}
+        bt["phoneme_labels"] = torch.zeros(B, 4, dtype=torch.int32).cuda()
+        batches.append(bt)
+
+    def run(pipelined):
+        model, _ = _build(meta, sd)
+        model.train()
+        # the random-weight recogniser must decode 1..59 phonemes: push the blank up until it does (as bench.py does)
+        with torch.no_grad():
+            blank = model.w2v2_pr._blank()
+            for _ in range(40):
+                n = [len(l) for bt in batches for l in model.w2v2_pr._decode(model.w2v2_pr._logits_eval(bt["audio_inputs"], bt["audio_lengths"].reshape(-1)[:, None])[0])]
+                if max(n) < 60 and min(n) >= 1:
+                    break
+                model.w2v2_pr.pr_head.bias[blank] += 0.25 if max(n) >= 60 else -0.25
+            else:
+                pytest.skip("no blank bias gives 1..59 phonemes on both batches")
+        model.w2v2_pr.wav2vec2._step = 100
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = Adam(params, lr=1e-4)
+        rec = []
+        for i in range(3):
+            bt, nb = batches[i % 2], batches[(i + 1) % 2]
+            opt.zero_grad(set_to_none=True)
+            ahead = (nb["audio_inputs"], nb["audio_lengths"]) if pipelined else None
+            out = model(0, **bt, _prefetch_next=ahead)
+            out["loss"].backward()
+            rec.append((out["loss"].detach().clone(), out["tvs_pred"].detach().clone(),
+                        [p.grad.detach().clone() for p in params], out["pred_ctc_phn_seq"]))
+            opt.step()
+        torch.cuda.synchronize()
+        return rec, model
+
+    inline, m0 = run(False)
+    names = [n for n, p in m0.named_parameters() if p.requires_grad]
+    piped, model = run(True)
+    for (l0, tv0, g0, s0), (l1, tv1, g1, s1) in zip(inline, piped):
+        assert torch.equal(l0, l1) and torch.equal(tv0, tv1)
+        # (the embedding gradient is a scatter-add with float atomics: its summation order varies run to run by itself)
+        diff = [(n, (a - b).abs().max().item(), a.abs().max().item()) for n, a, b in zip(names, g0, g1)
+                if not (torch.equal(a, b) or (n == "phn_emb_layer.weight" and torch.allclose(a, b, rtol=1e-5, atol=1e-6)))]
+        assert not diff, diff
+        assert all(np.array_equal(a, b) for a, b in zip(s0, s1))
+    # a stale prefetch (other tensor objects) is dropped, not used
+    other = {k: v.clone() for k, v in batches[0].items()}
+    model.prefetch(batches[1]["audio_inputs"], batches[1]["audio_lengths"])
+    out = model(0, **other)
+    assert model._prefetched is None and np.isfinite(out["loss"].item())
