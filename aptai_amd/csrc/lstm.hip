@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int cluster, k;
     if (!cluster_of_block(a.nclusters, cluster, k)) return;
+    // a latency chain of 499 dependent frames: when other streams' kernels share the CU (the frozen encoder of the next batch
+    // in the pipelined Force_APTAI step) these waves should win every issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     const int dir = cluster & 1, bg = a.bgroup0 + (cluster >> 1);
     const int j = lane & 15, q = lane >> 4;
     const int unit = k * 16 + wave * 4 + (j >> 2), gate = j & 3;
@@ -206,6 +209,9 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int cluster, k;
     if (!cluster_of_block(a.nclusters, cluster, k)) return;
+    // a latency chain of 499 dependent frames: when other streams' kernels share the CU (the frozen encoder of the next batch
+    // in the pipelined Force_APTAI step) these waves should win every issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     const int dir = cluster & 1, bg = a.bgroup0 + (cluster >> 1);
     const int j = lane & 15, q = lane >> 4;
     const int eb = tid & 15, eu = tid >> 4, unit = k * 16 + eu;

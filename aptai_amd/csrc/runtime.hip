@@ -64,3 +64,4 @@ const uint32_t* aptai_seed_salt(const void* stream) {
         if (g_salts[i].used && g_salts[i].stream == stream) return g_salts[i].ptr;
     return nullptr;
 }
+
