@@ -174,6 +174,8 @@ class Force_APTAI(nn.Module):
         for param in self.w2v2_pr.parameters():
             param.requires_grad = False
         self._enc_stream = None        # side stream of prefetch()
+        self._enc_graphs = {}          # batch shape -> captured encoder pass
+        self._enc_seen = {}
         self._prefetched = None
 
     # ------------------------------------------------------------------ shared body
@@ -201,16 +203,56 @@ class Force_APTAI(nn.Module):
         """Run the frozen recogniser for a batch on a side stream NOW; the next forward / _run called with these same tensors
         picks the result up instead of encoding inline.  The recogniser is frozen and runs in eval mode, so WHEN it runs does
         not change any result; running it for batch n+1 beside the heads of batch n fills the CUs the cooperating LSTM
-        kernels (32 workgroups for 3.5 ms) leave idle.  Each step still does one encoder pass and one heads pass."""
+        kernels (32 workgroups for 3.5 ms) leave idle.  Each step still does one encoder pass and one heads pass.
+        From the second call with a given batch shape on, the pass is ONE hipGraph launch (the recogniser has no trainable
+        state and no host-dependent control flow): the step was otherwise bound by the host's ~350 launches."""
+        dev = audio_inputs.device
         if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream(device=audio_inputs.device)
-        cur = torch.cuda.current_stream(audio_inputs.device)
+            self._enc_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
         self._enc_stream.wait_stream(cur)                              # the inputs (and the previous step's frees) are ordered first
+        key = (tuple(audio_inputs.shape), tuple(audio_lengths.shape), audio_inputs.dtype, audio_lengths.dtype,
+               getattr(self.w2v2_pr.wav2vec2, "_encoder_precision", "bf16"))
+        use_graph = os.environ.get("APTAI_FORCE_ENC_GRAPH", "1") != "0"
         with torch.cuda.stream(self._enc_stream):
-            enc = self._encode(audio_inputs, audio_lengths)
+            ge = self._enc_graphs.get(key) if use_graph else None
+            if ge is None and use_graph and self._enc_seen.get(key, 0) >= 1:
+                ge = self._capture_encoder(key, audio_inputs, audio_lengths)
+            if ge is not None:
+                ge.audio.copy_(audio_inputs, non_blocking=True)
+                ge.lengths.copy_(audio_lengths, non_blocking=True)
+                ge.graph.replay()
+                self.w2v2_pr.wav2vec2._step += 1                       # what the eager pass does on the host
+                o = ge.out
+                # the graph's outputs are overwritten by the next replay: hand out copies (13 MB, 4 us)
+                enc = SimpleNamespace(g=o.g, ac=o.ac.clone(), ids=o.ids.clone(), nlen=o.nlen.clone(), frame_lens=o.frame_lens.clone(),
+                                      step=self.w2v2_pr.wav2vec2._step)
+            else:
+                enc = self._encode(audio_inputs, audio_lengths)
+                self._enc_seen[key] = self._enc_seen.get(key, 0) + 1
             enc.event = torch.cuda.Event()
             enc.event.record(self._enc_stream)
         self._prefetched = (audio_inputs, audio_lengths, enc)
+
+    def _capture_encoder(self, key, audio_inputs, audio_lengths):
+        """hipGraph of _encode for one batch shape, captured on the side stream (an eager pass with this shape has already run:
+        weight copies and scratch buffers exist).  Falls back to eager launches if the capture fails."""
+        ge = SimpleNamespace(audio=audio_inputs.clone(), lengths=audio_lengths.clone(), graph=torch.cuda.CUDAGraph(), out=None)
+        try:
+            step0 = self.w2v2_pr.wav2vec2._step
+            torch.cuda.synchronize(audio_inputs.device)
+            with torch.cuda.graph(ge.graph, stream=self._enc_stream):
+                ge.out = self._encode(ge.audio, ge.lengths)
+            self.w2v2_pr.wav2vec2._step = step0                        # capturing issued nothing
+        except Exception as e:                                         # noqa: BLE001 - keep training, eagerly
+            import warnings
+            warnings.warn(f"Force_APTAI: encoder hipGraph capture failed ({e!r}); the prefetch stays eager")
+            torch.cuda.synchronize(audio_inputs.device)
+            self._enc_graphs[key] = None
+            self._enc_seen[key] = -(1 << 30)
+            return None
+        self._enc_graphs[key] = ge
+        return ge
 
     def _take_prefetched(self, audio_inputs, audio_lengths):
         pf, self._prefetched = self._prefetched, None
