@@ -39,6 +39,7 @@ struct AttnArgs {
     bf16_t* dqkv;
     int skip_pad_q;
     int stagger;                    // experiment: s_sleep units (64 clocks) per wave-slot index at kernel start
+    int q_prescaled;                // the Q third of qkv already carries scale * log2(e) (QKV GEMM epilogue): scores arrive in the exp2 domain
 };
 
 // ---- LDS tile [rows][64] bf16, 128-B rows, 16-B chunk index XORed with tile_swz(row) = row bits (2, 3, 1) -> swizzle bits
@@ -349,6 +350,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 
 // ================================================================================== backward: dK, dV
 // grid (Tp/128, heads, B); wave w owns keys key0 = kt*128 + w*32 .. +31; loops over 32-query tiles.
+// PRE: Q arrives pre-multiplied by scale * log2(e), so S = Q K^T is already the exp2 argument up to the row constant; the S and dP
+// accumulators START at -lse2 and -delta (read from LDS straight into the MFMA C operand: no instruction), which removes the
+// FMA in front of every exponential and the subtraction behind every dP.
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES + 384];   // staging; Q tile, dO tile (32 queries each)
     char* sQ = smem;
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         __syncthreads();
         *(u32x4*)(sQ + soff) = qreg;
         *(u32x4*)(sD + soff) = dreg;
-        if (tid < 16) *(f32x4*)(sL + tid * 4) = sreg;
+        if (tid < 16) *(f32x4*)(sL + tid * 4) = PRE ? -sreg : sreg;
         if (a.thr16 && tid >= 32 && tid < 64) ((uint32_t*)sL)[64 + (tid & 31)] = hreg;
         __syncthreads();
         if (t + 1 < nq) {
@@ -430,22 +435,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
             if (a.thr16 && tid >= 32 && tid < 64) hreg = rng_hash(rowid0 + (uint32_t)((t + 1) * 32), a.seed0, a.seed1);
         }
         // S[q][key] and dP[q][key]
-        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sQ, lo, 0, 0), kf[0], (f32x16)(0.f), 0, 0, 0);
-        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sD, lo, 0, 0), vf[0], (f32x16)(0.f), 0, 0, 0);
+        f32x16 cs = (f32x16)(0.f), cd = (f32x16)(0.f);        // PRE: -lse2 / -delta of the 16 query rows this lane holds
+        if (PRE) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 l4 = *(const f32x4*)(sL + 8 * g4 + 4 * h);
+                const f32x4 d4 = *(const f32x4*)(sL + 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) { cs[4 * g4 + rr] = l4[rr]; cd[4 * g4 + rr] = d4[rr]; }
+            }
+        }
+        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sQ, lo, 0, 0), kf[0], cs, 0, 0, 0);
+        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sD, lo, 0, 0), vf[0], cd, 0, 0, 0);
 #pragma unroll
         for (int ds = 1; ds < 4; ++ds) {
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sQ, lo, 0, ds), kf[ds], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sD, lo, 0, ds), vf[ds], dp, 0, 0, 0);
         }
-        float pd[16], dsv[16];
+        float pd[16], dsv[16];                                 // P and dS / dscale (see below); dsv starts as delta (!PRE)
+        if (PRE) {
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 l4 = *(const f32x4*)(sL + 8 * g4 + 4 * h);
-            const f32x4 d4 = *(const f32x4*)(sL + 32 + 8 * g4 + 4 * h);
+            for (int r = 0; r < 16; ++r) pd[r] = fast_exp2(s[r]);
+        } else {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                pd[4 * g4 + rr] = fast_exp2(fmaf(s[4 * g4 + rr], c, -l4[rr]));
-                dsv[4 * g4 + rr] = d4[rr];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 l4 = *(const f32x4*)(sL + 8 * g4 + 4 * h);
+                const f32x4 d4 = *(const f32x4*)(sL + 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    pd[4 * g4 + rr] = fast_exp2(fmaf(s[4 * g4 + rr], c, -l4[rr]));
+                    dsv[4 * g4 + rr] = d4[rr];
+                }
             }
         }
         if (wave_boundary) {                                   // wave-uniform: only the wave holding key len-1 masks
@@ -466,13 +486,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
                     const float p0 = pd[r];
                     // dS = dscale * P (keep * dP - delta / dscale), P_drop = dscale * keep * P: the dQ kernel left delta / dscale
                     // in a.delta and the 1/(1-p) factors are applied once to dK and dV in the epilogue
-                    dsv[r] = p0 * ((k ? dp[r] : 0.f) - dsv[r]);
+                    if (PRE) dsv[r] = p0 * (k ? dp[r] : cd[r]);          // dp = dP - delta already; a dropped element keeps -delta
+                    else dsv[r] = p0 * ((k ? dp[r] : 0.f) - dsv[r]);
                     pd[r] = k ? p0 : 0.f;
                 }
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dsv[r] = pd[r] * (dp[r] - dsv[r]);
+            for (int r = 0; r < 16; ++r) dsv[r] = PRE ? pd[r] * dp[r] : pd[r] * (dp[r] - dsv[r]);
         }
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
@@ -487,12 +508,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     }
     __syncthreads();                                           // the Q / dO tiles become the epilogue staging area
     char* sw = smem + wave * (32 * OUT_PITCH);
-    store_rows_bf16(sw, dKT, a.scale * a.dscale, dK0 + (long)(wave * 32) * a.ld, a.ld, lane);
+    // dK = scale * dS^T Q; with PRE the staged rows are Q' = scale * log2(e) * Q, so the factor left over is ln 2
+    store_rows_bf16(sw, dKT, (PRE ? 0.6931471805599453f : a.scale) * a.dscale, dK0 + (long)(wave * 32) * a.ld, a.ld, lane);
     store_rows_bf16(sw, dVT, a.dscale, dV0 + (long)(wave * 32) * a.ld, a.ld, lane);
 }
 
 // ================================================================================== backward: dQ
 // grid (Tp/128, heads, B); wave w owns queries q0 = qt*128 + w*32 .. +31; loops over 32-key tiles.
+template <bool PRE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES + 512];   // prologue / epilogue staging; K, V tiles (32 keys)
     char* sK = smem;
@@ -565,6 +588,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
     uint32_t hbase = 0;                      // dropout: row hash of this lane's query + 2 h K1 (see the forward kernel)
     if (a.thr16) hbase = rng_hash((uint32_t)((b * a.heads + hd) * a.Tp + q), a.seed0, a.seed1) + (uint32_t)(2 * h) * ATTN_K1;
     const float c = a.c;
+    const f32x16 cs = (f32x16)(PRE ? -lse_q : 0.f), cd = (f32x16)(PRE ? -del_q : 0.f);
     for (int t = 0; t < nk; ++t) {
         __syncthreads();
         *(u32x4*)(sK + soff) = kreg;
@@ -574,8 +598,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
             kreg = *(const u32x4*)(Kb + (long)(t + 1) * 32 * a.ld + gk);
             vreg = *(const u32x4*)(Vb + (long)(t + 1) * 32 * a.ld + gk);
         }
-        f32x16 sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sK, lo, 0, 0), qf[0], (f32x16)(0.f), 0, 0, 0);
-        f32x16 dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sV, lo, 0, 0), df[0], (f32x16)(0.f), 0, 0, 0);
+        f32x16 sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sK, lo, 0, 0), qf[0], cs, 0, 0, 0);      // PRE: starts at -lse2
+        f32x16 dpT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sV, lo, 0, 0), df[0], cd, 0, 0, 0);     // PRE: starts at -delta
 #pragma unroll
         for (int ds = 1; ds < 4; ++ds) {
             sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sK, lo, 0, ds), qf[ds], sT, 0, 0, 0);
@@ -585,20 +609,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
         const bool boundary = t * 32 + 32 > len;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float p = fast_exp2(fmaf(sT[r], c, -lse_q));
+            float p = PRE ? fast_exp2(sT[r]) : fast_exp2(fmaf(sT[r], c, -lse_q));
             if (boundary && (t * 32 + acc_row(r, h) >= len)) p = 0.f;
             dsv[r] = p;
         }
         if (a.thr16) {
+            const float dropped = PRE ? -del_q : 0.f;                 // PRE: dpT = dP - delta already; a dropped element keeps -delta
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const uint32_t hsh = attn_mix(hbase + (uint32_t)(t * 16 + acc_row(r, 0) / 2) * ATTN_K1);
-                dpT[r] = (hsh & 0xffffu) >= a.thr16 ? dpT[r] : 0.f;
-                dpT[r + 1] = (hsh >> 16) >= a.thr16 ? dpT[r + 1] : 0.f;
+                dpT[r] = (hsh & 0xffffu) >= a.thr16 ? dpT[r] : dropped;
+                dpT[r + 1] = (hsh >> 16) >= a.thr16 ? dpT[r + 1] : dropped;
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dsv[r] *= (dpT[r] - del_q);
+        for (int r = 0; r < 16; ++r) dsv[r] *= PRE ? dpT[r] : (dpT[r] - del_q);
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
             const bf16x8 dsf = pack8(&dsv[8 * sstep]);
@@ -613,14 +638,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens, int64_t B, int64_t Tp, int64_t H,
-              int64_t heads, float scale, float dropout_p, uint64_t seed, const void* stream) {
+              int64_t heads, float scale, float dropout_p, uint64_t seed, int q_prescaled, const void* stream) {
     APTAI_REQUIRE(qkv && lens, "%s: null pointer", who);
     APTAI_REQUIRE(B > 0 && Tp > 0 && Tp % 128 == 0, "%s: frames per utterance (%ld) must be a positive multiple of 128", who, (long)Tp);
     APTAI_REQUIRE(heads > 0 && H == heads * HD, "%s: head_dim must be 64 (H=%ld heads=%ld)", who, (long)H, (long)heads);
     memset(&a, 0, sizeof(a));
     a.qkv = (const bf16_t*)qkv; a.ld = 3 * H; a.lens = lens; a.ldo = H;
     a.B = (int)B; a.Tp = (int)Tp; a.H = (int)H; a.heads = (int)heads;
-    a.scale = scale; a.c = scale * LOG2E;
+    a.scale = scale; a.c = q_prescaled ? 1.0f : scale * LOG2E;
+    a.q_prescaled = q_prescaled;
     a.thr16 = drop_thr16(dropout_p); a.dscale = drop_scale(a.thr16);
     a.seed0 = (uint32_t)seed; a.seed1 = (uint32_t)(seed >> 32);
     a.salt = aptai_seed_salt(stream);
@@ -633,9 +659,9 @@ int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens
 
 extern "C" int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* ctx, float* lse2, float* ctx_f32, int64_t B,
                                    int64_t Tp, int64_t H, int64_t heads, float scale, float dropout_p, uint64_t seed,
-                                   void* stream_) {
+                                   int q_prescaled, void* stream_) {
     AttnArgs a;
-    int rc = fill_args(a, "aptai_attention_fwd", qkv, lens, B, Tp, H, heads, scale, dropout_p, seed, stream_);
+    int rc = fill_args(a, "aptai_attention_fwd", qkv, lens, B, Tp, H, heads, scale, dropout_p, seed, q_prescaled, stream_);
     if (rc) return rc;
     APTAI_REQUIRE(ctx != nullptr, "aptai_attention_fwd: null ctx");
     a.ctx = (bf16_t*)ctx; a.lse2 = lse2; a.o32 = ctx_f32;
@@ -652,19 +678,26 @@ extern "C" int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* c
 
 extern "C" int aptai_attention_bwd(const void* qkv, const int32_t* lens, const void* ctx, const float* ctx_f32, const void* dctx,
                                    const float* lse2, float* delta_ws, void* dqkv, int64_t B, int64_t Tp, int64_t H,
-                                   int64_t heads, float scale, float dropout_p, uint64_t seed, int dctx_zero_beyond_len, void* stream_) {
+                                   int64_t heads, float scale, float dropout_p, uint64_t seed, int dctx_zero_beyond_len,
+                                   int q_prescaled, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AttnArgs a;
-    int rc = fill_args(a, "aptai_attention_bwd", qkv, lens, B, Tp, H, heads, scale, dropout_p, seed, stream_);
+    int rc = fill_args(a, "aptai_attention_bwd", qkv, lens, B, Tp, H, heads, scale, dropout_p, seed, q_prescaled, stream_);
     if (rc) return rc;
     APTAI_REQUIRE(ctx && dctx && lse2 && delta_ws && dqkv, "aptai_attention_bwd: null pointer");
     a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.lse2 = (float*)lse2; a.delta = delta_ws; a.o32 = (float*)ctx_f32; a.dqkv = (bf16_t*)dqkv;
     a.skip_pad_q = dctx_zero_beyond_len;
     dim3 grid((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B);
     // dQ first: it computes delta for its own queries and leaves it in delta_ws for the dK/dV kernel
-    APTAI_LAUNCH(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, a);
-    APTAI_CHECK_LAUNCH("attn_bwd_dq_kernel");
-    APTAI_LAUNCH(attn_bwd_dkdv_kernel, grid, dim3(256), 0, stream, a);
+    if (q_prescaled) {
+        APTAI_LAUNCH(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, stream, a);
+        APTAI_CHECK_LAUNCH("attn_bwd_dq_kernel");
+        APTAI_LAUNCH(attn_bwd_dkdv_kernel<true>, grid, dim3(256), 0, stream, a);
+    } else {
+        APTAI_LAUNCH(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, stream, a);
+        APTAI_CHECK_LAUNCH("attn_bwd_dq_kernel");
+        APTAI_LAUNCH(attn_bwd_dkdv_kernel<false>, grid, dim3(256), 0, stream, a);
+    }
     APTAI_CHECK_LAUNCH("attn_bwd_dkdv_kernel");
     return APTAI_OK;
 }

@@ -57,6 +57,7 @@ struct GemmArgs {
     long slab_stride;           // elements between split-K slabs (fp32 out only)
     int tiles_m, tiles_n;
     int raster_gm;              // tile rows per raster group (raster2d); 0 = row-major walk
+    int colscale_n; float colscale;   // columns [0, colscale_n) of the bf16 output are multiplied by colscale (after alpha / bias)
     // 2-level batching: blockIdx.y = outer * nb_inner + inner; element offsets per level
     int nb_inner;
     long sA[2], sB[2], sC[2], sBias[2], sR[2], sAux[2];
@@ -82,6 +83,10 @@ __device__ __forceinline__ void gelu_fast_both(float x, float& y, float& dy) {
 __device__ __forceinline__ void epilogue_chunk(float (&v)[8], const GemmArgs& g, const int flags, const long m, const int n,
                                                const u32x4 auxq, const u32x4 resq, const uint32_t sd0, const uint32_t sd1) {
     const bool pre_dgelu = (flags & APTAI_EPI_PRE_DGELU) != 0;
+    if (n < g.colscale_n) {                                    // 8-column chunks: colscale_n % 8 == 0 (checked on the host)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= g.colscale;
+    }
     float d[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) d[r] = 1.0f;
@@ -1191,6 +1196,8 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     if (d->flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) APTAI_REQUIRE(d->aux != nullptr, "aptai_gemm_bf16: EPI_DGELU / EPI_MUL_AUX without aux");
     if (d->flags & APTAI_EPI_PRE_DGELU) APTAI_REQUIRE(d->out_pre != nullptr && (d->flags & APTAI_EPI_GELU), "aptai_gemm_bf16: EPI_PRE_DGELU needs EPI_GELU and out_pre");
 
+    APTAI_REQUIRE(d->colscale_n >= 0 && d->colscale_n % 8 == 0 && d->colscale_n <= d->N && (d->colscale_n == 0 || !d->out_f32),
+                  "aptai_gemm_bf16: colscale_n must be a multiple of 8 within N, bf16 output only");
     memset(&g, 0, sizeof(g));
     g.A = (const bf16_t*)d->A; g.lda = d->lda;
     g.B = (const bf16_t*)d->B; g.ldb = d->ldb;
@@ -1207,6 +1214,7 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     g.dscale = drop_scale(g.thr16);
     if (g.thr16 == 0) g.flags &= ~APTAI_EPI_DROPOUT;
     g.alpha = d->alpha;
+    g.colscale_n = d->colscale_n; g.colscale = d->colscale;
     g.tiles_m = (int)ceil_div(d->M, BM);
     g.tiles_n = (int)ceil_div(d->N, BN);
     {

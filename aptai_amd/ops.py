@@ -27,7 +27,7 @@ class GemmDesc(ctypes.Structure):
                 ("batch_outer", c_int), ("batch_inner", c_int),
                 ("batch_stride_a", c_i64 * 2), ("batch_stride_b", c_i64 * 2), ("batch_stride_c", c_i64 * 2),
                 ("batch_stride_bias", c_i64 * 2), ("batch_stride_res", c_i64 * 2), ("batch_stride_aux", c_i64 * 2),
-                ("tile", c_int)]
+                ("tile", c_int), ("colscale_n", c_int), ("colscale", c_float)]
 
 
 class GemmProbe:
@@ -73,7 +73,7 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
                a_kmajor=False, b_kmajor=False, out_f32=False, bias=None, gelu=False, residual=None, out_pre=None,
                dgelu_aux=None, alpha: Optional[float] = None, dropout_p: float = 0.0, seed: int = 0, split_k: int = 1,
                accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None, tile: int = 0,
-               ldaux=None, pre_dgelu: bool = False, mul_aux=None):
+               ldaux=None, pre_dgelu: bool = False, mul_aux=None, colscale=None):
     """Fills one aptai_gemm_desc in place; returns (out, workspace) - the caller keeps them alive across the launch."""
     _dev(a, b, out, bias, residual, out_pre, dgelu_aux, mul_aux)
     if out is None:
@@ -111,6 +111,8 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
     d.flags = flags
     d.split_k, d.accumulate = split_k, int(accumulate)
     d.tile = tile
+    if colscale is not None:       # (n_cols, factor): output columns [0, n_cols) *= factor after alpha / bias
+        d.colscale_n, d.colscale = int(colscale[0]), float(colscale[1])
     if ldaux is not None:
         d.ldaux = ldaux
     if ldr is not None:
@@ -247,17 +249,26 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dres=None, dropout_p=0.0, seed=0,
 
 
 # ----------------------------------------------------------------------------- attention
-def attention_fwd(qkv, lens_i32, B, Tp, H, heads, *, dropout_p=0.0, seed=0, save_lse=True):
+ATTN_LOG2E = 1.4426950408889634
+
+
+def attention_qscale(H: int, heads: int) -> float:
+    """The factor the fused q|k|v projection applies to its Q columns (gemm(..., colscale=(H, this))) for q_prescaled attention."""
+    return (H // heads) ** -0.5 * ATTN_LOG2E
+
+
+def attention_fwd(qkv, lens_i32, B, Tp, H, heads, *, dropout_p=0.0, seed=0, save_lse=True, q_prescaled=False):
     _dev(qkv, lens_i32)
     ctx = torch.empty((B * Tp, H), device=qkv.device, dtype=torch.bfloat16)
     lse2 = torch.empty((B, heads, Tp), device=qkv.device, dtype=torch.float32) if save_lse else None
     ctx32 = torch.empty((B * Tp, H), device=qkv.device, dtype=torch.float32) if save_lse else None
     _lib.call("aptai_attention_fwd", qkv.data_ptr(), lens_i32.data_ptr(), ctx.data_ptr(), _ptr(lse2), _ptr(ctx32), B, Tp, H,
-              heads, (H // heads) ** -0.5, dropout_p, seed, _stream())
+              heads, (H // heads) ** -0.5, dropout_p, seed, int(q_prescaled), _stream())
     return ctx, (lse2, ctx32) if save_lse else None
 
 
-def attention_bwd(qkv, lens_i32, ctx, dctx, stats, B, Tp, H, heads, *, dropout_p=0.0, seed=0, dctx_zero_beyond_len=False):
+def attention_bwd(qkv, lens_i32, ctx, dctx, stats, B, Tp, H, heads, *, dropout_p=0.0, seed=0, dctx_zero_beyond_len=False,
+                  q_prescaled=False):
     """``stats`` = the (lse2, ctx_f32) pair returned by attention_fwd."""
     lse2, ctx32 = stats
     _dev(qkv, lens_i32, ctx, dctx, lse2)
@@ -265,7 +276,7 @@ def attention_bwd(qkv, lens_i32, ctx, dctx, stats, B, Tp, H, heads, *, dropout_p
     delta = torch.empty((B, heads, Tp), device=qkv.device, dtype=torch.float32)
     _lib.call("aptai_attention_bwd", qkv.data_ptr(), lens_i32.data_ptr(), ctx.data_ptr(), _ptr(ctx32), dctx.data_ptr(), lse2.data_ptr(),
               delta.data_ptr(), dqkv.data_ptr(), B, Tp, H, heads, (H // heads) ** -0.5, dropout_p, seed,
-              int(dctx_zero_beyond_len), _stream())
+              int(dctx_zero_beyond_len), int(q_prescaled), _stream())
     return dqkv
 
 

@@ -138,8 +138,10 @@ class _LayerImpl:
             s.n1 = n1
         else:
             attn_in = x
-        s.qkv = ops.gemm(attn_in, w.wqkv, M, 3 * H, H, bias=w.bqkv)
-        s.ctx, s.lse = ops.attention_fwd(s.qkv, self.lens, g.B, g.Tp, H, cfg.num_attention_heads, dropout_p=p_att,
+        # the projection's epilogue hands Q over as q * head_dim^-0.5 * log2(e) (rounded once): the attention kernels then see
+        # their exp2 arguments directly (q_prescaled)
+        s.qkv = ops.gemm(attn_in, w.wqkv, M, 3 * H, H, bias=w.bqkv, colscale=(H, ops.attention_qscale(H, cfg.num_attention_heads)))
+        s.ctx, s.lse = ops.attention_fwd(s.qkv, self.lens, g.B, g.Tp, H, cfg.num_attention_heads, q_prescaled=True, dropout_p=p_att,
                                          seed=_seed(self.seed, 1), save_lse=need)
         s.s1 = ops.gemm(s.ctx, w.wo, M, H, H, bias=w.bo, residual=x, dropout_p=p_h, seed=_seed(self.seed, 2))
         if pre:
@@ -242,7 +244,7 @@ class _LayerImpl:
             dwo, dbo = on_side(lambda: (ops.gemm(d_att_out, s.ctx, H, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk[1]),
                                         ops.colsum(d_att_out, M, H)))
         dctx = ops.gemm(d_att_out, w.wo, M, H, H, b_kmajor=True)
-        dqkv = ops.attention_bwd(s.qkv, self.lens, s.ctx, dctx, s.lse, g.B, g.Tp, H, heads, dropout_p=p_att,
+        dqkv = ops.attention_bwd(s.qkv, self.lens, s.ctx, dctx, s.lse, g.B, g.Tp, H, heads, q_prescaled=True, dropout_p=p_att,
                                  seed=_seed(self.seed, 1), dctx_zero_beyond_len=True)
         attn_in = s.n1 if pre else s.x
         if not grouped:

@@ -79,6 +79,9 @@ typedef struct {
         batch_stride_aux[2];
     int tile;                       /* 0 = auto, 64 = 64x128 tile (3 blocks/CU, K-contiguous A), 128 = 128x128 tile kernel (2 blocks/CU), 192 = 128x192 tile, 3-stage ring
                                        (1 block/CU), 256 = 256x256 deep-pipelined kernel */
+    int colscale_n; float colscale; /* bf16 output: columns [0, colscale_n) *= colscale after alpha / bias (colscale_n % 8 == 0).  The fused
+                                       q|k|v projection (HF:495-498) hands the attention kernels Q already multiplied by
+                                       head_dim^-0.5 * log2(e) (HF:522 applies the scaling to the projected query too), rounded once */
 } aptai_gemm_desc;
 
 int aptai_gemm_bf16(const aptai_gemm_desc* desc, void* stream);
@@ -110,14 +113,17 @@ int64_t aptai_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
  * masked, HF:678-688); Tp % 128 == 0; ctx [B*Tp][H] bf16; lse2 fp32 [B][heads][Tp] (log2-domain log-sum-exp).
  * dropout_p: attention-probability dropout (HF:458), mask from (seed, (b,h,q,k)).
  * ctx_f32 (optional, [B*Tp][H] fp32): unrounded context; the backward's delta = rowsum(dO*O) is a small-difference term
- * (dS = P*(dP - delta)) whose bf16 rounding would otherwise dominate the q/k gradients when attention is diffuse. */
+ * (dS = P*(dP - delta)) whose bf16 rounding would otherwise dominate the q/k gradients when attention is diffuse.
+ * q_prescaled != 0: the Q third of qkv already carries scale * log2(e) (aptai_gemm_desc.colscale of the fused q|k|v projection):
+ * the scores arrive in the exp2 domain, the backward starts its S / dP accumulators at -lse2 / -delta, and dqkv's Q third is
+ * still the gradient with respect to the UNSCALED projection output (what the projection's own backward expects). */
 int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* ctx, float* lse2, float* ctx_f32, int64_t B, int64_t Tp,
-                        int64_t H, int64_t heads, float scale, float dropout_p, uint64_t seed, void* stream);
+                        int64_t H, int64_t heads, float scale, float dropout_p, uint64_t seed, int q_prescaled, void* stream);
 /* delta_ws: fp32 [B][heads][Tp] scratch.  dctx_zero_beyond_len=1 lets the kernel skip query rows >= lens[b]
  * (their incoming gradient is exactly zero in the models: no loss term touches padded frames). */
 int aptai_attention_bwd(const void* qkv, const int32_t* lens, const void* ctx, const float* ctx_f32, const void* dctx,
                         const float* lse2, float* delta_ws, void* dqkv, int64_t B, int64_t Tp, int64_t H, int64_t heads, float scale,
-                        float dropout_p, uint64_t seed, int dctx_zero_beyond_len, void* stream);
+                        float dropout_p, uint64_t seed, int dctx_zero_beyond_len, int q_prescaled, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ parameter prep
  * fp32 master parameters -> bf16 compute copies (and the layouts the kernels want). */

@@ -20,7 +20,9 @@ def main():
             t = bench(lambda: ops.attention_fwd(qkv, lens, B, Tp, H, heads, dropout_p=p, seed=1))
             ctx, st = ops.attention_fwd(qkv, lens, B, Tp, H, heads, dropout_p=p, seed=1)
             tb = bench(lambda: ops.attention_bwd(qkv, lens, ctx, dctx, st, B, Tp, H, heads, dropout_p=p, seed=1, dctx_zero_beyond_len=True))
-            row.append(f"len {L}: fwd {t:5.1f} bwd {tb:5.1f}")
+            tp = bench(lambda: ops.attention_bwd(qkv, lens, ctx, dctx, st, B, Tp, H, heads, dropout_p=p, seed=1, dctx_zero_beyond_len=True,
+                                                 q_prescaled=True))
+            row.append(f"len {L}: fwd {t:5.1f} bwd {tb:5.1f} bwd(prescaled q) {tp:5.1f}")
         print(f"stagger={os.environ.get('APTAI_ATTN_STAGGER', '0')} p={p}: " + " | ".join(row), flush=True)
 
 
