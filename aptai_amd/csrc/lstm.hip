@@ -45,6 +45,11 @@ struct LstmArgs {
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate nonlinearities on the step's critical path: bare v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the libm expf / tanhf and
+// an IEEE divide (~150 instructions per frame and lane): sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e))
+// (absolute error ~1e-7; saturates correctly through inf / 0).
+__device__ __forceinline__ float sigm_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 template <int SRC>
 __device__ __forceinline__ float quad_bcast(float v) {                   // value of lane (quad base + SRC)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), SRC * 0x55, 0xf, 0xf, true));
@@ -172,10 +177,10 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
             __syncthreads();                                            // the image is free for the next frame's gather
         }
         // ---- the four gates of (utterance 4q + slot, unit) sit in the four lanes of the quad, register = slot: 4 x 4 transpose
-        const float gi = sigm(quad_pick<0>(acc, gate)), gf = sigm(quad_pick<1>(acc, gate)), gg = tanhf(quad_pick<2>(acc, gate)),
-                    go = sigm(quad_pick<3>(acc, gate));
+        const float gi = sigm_fast(quad_pick<0>(acc, gate)), gf = sigm_fast(quad_pick<1>(acc, gate)),
+                    gg = tanh_fast(quad_pick<2>(acc, gate)), go = sigm_fast(quad_pick<3>(acc, gate));
         const float c_new = gf * c_st + gi * gg;
-        const float h_new = go * tanhf(c_new);
+        const float h_new = go * tanh_fast(c_new);
         const bool act = s < mylen;
         if (act) { c_st = c_new; h_st = h_new; }
         __builtin_amdgcn_raw_buffer_store_b32(word30(tau(s), h_st), rsrc, (unsigned)(((s & 1) * 4096 + unit * 16 + myrow) * 4), 0, 16);
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
             if (s > 0) cprev = a.cstate_in[((row + (dir ? 1 : -1)) * 2 + dir) * LH + unit];
             dho = a.dhout[row * 2 * LH + dir * LH + unit];
         }
+        const float tc = tanh_fast(c);                                // needs only this frame's loads: off the exchange's critical path
         float dh_rec = 0.f;
         if (n > 0) {
             // partial sums of iteration n-1 for this workgroup's units: [src 16][unit_l 16][batch 16], thread = (eu, eb)
@@ -271,7 +277,6 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
         float pi = 0.f, pf = 0.f, pg = 0.f, po = 0.f;
         if (act) {
             const float dh = dho + dh_rec;
-            const float tc = tanhf(c);
             const float d_o = dh * tc;
             dc += dh * go * (1.f - tc * tc);
             const float d_i = dc * gg, d_g = dc * gi, d_f = dc * cprev;
