@@ -146,7 +146,11 @@ __device__ __forceinline__ bool attn_keep(uint32_t pair, int key, uint32_t s0, u
 //   * 2-deep LDS ring, ONE barrier per tile.
 constexpr int FWD_BUF = 2 * 64 * 128;                           // one K tile + one V tile (64 keys each)
 constexpr int FWD_SMEM = 2 * FWD_BUF;                           // 2-deep ring, 32 KB (>= the 18 KB of epilogue staging)
-constexpr float REF_SUM_LIMIT = 16384.0f;
+// The reference sits REF_HEADROOM binades ABOVE the maximum it was taken from (floating point is scale-free: p ~ 2^-40 costs no
+// accuracy in fp32 sums or in the bf16 P operand, which has the fp32 exponent range), so a score has to jump 2^(127+40) over
+// everything seen before it, within one 64-key tile, to overflow; scores 2^86 below the reference flush to zero, as they should.
+constexpr float REF_HEADROOM = 40.0f;
+constexpr float REF_SUM_LIMIT = 1.4901161193847656e-08f;         // 2^-26 = 2^(14 - REF_HEADROOM)
 
 template <bool V> struct Flag { static constexpr bool value = V; };
 
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sT[1][r]);
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            ref = mt * c;
+            ref = fmaf(mt, c, REF_HEADROOM);
         }
         float psum = 0.f;
 #pragma unroll
@@ -283,14 +287,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         }
         psum += __shfl_xor(psum, 32, 64);
         l_run += psum;
-        // the reference moves only when a row sum says some p passed 2^14 / 64 (or overflowed): exact power-of-two rescale of
-        // O and l (this tile's products included), applied after the fact - rare, wave-uniform
+        // the reference moves only when a row sum says some p passed 2^14 times the level of the previous maximum: exact
+        // power-of-two rescale of O and l (this tile's products included) back to the headroom level, applied after the fact -
+        // rare, wave-uniform.  (A row that overflowed all the same - a 2^167 jump inside one tile - turns into inf / NaN in lse
+        // and ctx rather than into a silently wrong row.)
         if (!FIRST && __builtin_amdgcn_ballot_w64(!(psum <= REF_SUM_LIMIT))) {
             if (!(psum <= REF_SUM_LIMIT)) {
-                // (an overflowed row - psum = inf - cannot be repaired in place; the 2^14 margin makes that a 2^114 jump
-                //  of one score over everything before it, outside what bf16 Q K^T with |s| < 2^17 can produce per tile... it is
-                //  still flagged: the lse becomes inf and the context row NaN instead of silently wrong.)
-                const float e = floorf(fast_log2(psum));
+                const float e = floorf(fast_log2(psum)) + REF_HEADROOM;
                 const float sc = fast_exp2(-e);
                 ref += e;
                 l_run *= sc;
