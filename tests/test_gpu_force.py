@@ -359,9 +359,12 @@ def test_force_aptai_prefetched_encoder_is_bit_identical_to_inline():
     piped, model = run(True)
     for (l0, tv0, g0, s0), (l1, tv1, g1, s1) in zip(inline, piped):
         assert torch.equal(l0, l1) and torch.equal(tv0, tv1)
-        # (the embedding gradient is a scatter-add with float atomics: its summation order varies run to run by itself)
+        # (two kernels sum with float atomics - the embedding scatter-add and the per-label occupancy sums of the forward-sum
+        #  CTC gradient, csrc/ctc.hip - so everything on the ALIGNMENT path varies in its last bits from run to run by itself;
+        #  the parameters behind the LSTM, the losses and the predictions must be equal)
+        atomic_path = ("phn_emb_layer.", "xatt.", "frame_lin.")
         diff = [(n, (a - b).abs().max().item(), a.abs().max().item()) for n, a, b in zip(names, g0, g1)
-                if not (torch.equal(a, b) or (n == "phn_emb_layer.weight" and torch.allclose(a, b, rtol=1e-5, atol=1e-6)))]
+                if not (torch.equal(a, b) or (n.startswith(atomic_path) and torch.allclose(a, b, rtol=1e-5, atol=1e-6)))]
         assert not diff, diff
         assert all(np.array_equal(a, b) for a, b in zip(s0, s1))
     # a stale prefetch (other tensor objects) is dropped, not used
