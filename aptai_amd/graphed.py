@@ -28,6 +28,7 @@ import torch
 
 from . import _lib, hostlogic, ops
 from .aptai import APTAI, heads_bwd, heads_fwd
+from .w2v2_pr import Wav2Vec2_PR, pr_head_bwd, pr_head_fwd
 from .wav2vec2 import _FinalLNImpl, _FrontImpl, _LayerImpl, _seed
 
 
@@ -51,7 +52,7 @@ def _unbind_salt(stream_handle: int) -> None:
 
 
 class GraphedAPTAIStep:
-    def __init__(self, model: APTAI, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], reducer=None):
+    def __init__(self, model, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], reducer=None):
         assert model.training, "call model.train() first"
         self.model, self.opt, self.reducer = model, optimizer, reducer
         # data parallel: gradients are averaged per graph segment (dp.GradGroupReducer), overlapped with the next segment
@@ -64,17 +65,26 @@ class GraphedAPTAIStep:
         cfg = self.cfg
         dev = next(model.parameters()).device
         self.dev = dev
-        if any(p.requires_grad for p in w.feature_extractor.parameters()):
-            raise NotImplementedError("GraphedAPTAIStep captures the frozen-feature-encoder configuration (APTAI's default)")
+        # two model kinds share the segments: APTAI (regression + frame classification heads, models/aptai.py) and Wav2Vec2_PR
+        # (CTC head, models/w2v2_pr.py).  A trainable feature encoder (the recogniser's fine-tuning,
+        # train/train_phoneme_recognizer.py) adds its backward to the front-backward segment.
+        self.kind = "pr" if isinstance(model, Wav2Vec2_PR) else "aptai"
+        self.train_conv = any(p.requires_grad for p in w.feature_extractor.parameters())
         # ---- static inputs
-        self.audio = batch["audio_inputs"].float().contiguous().clone()
+        audio_key = "input_values" if self.kind == "pr" else "audio_inputs"
+        self.audio = batch[audio_key].float().contiguous().clone()
         B, S = self.audio.shape
         self.g = w._geometry(B, S)
         g = self.g
         self.lens_i32 = torch.zeros(B, device=dev, dtype=torch.int32)
         self.spec = torch.zeros((B, g.T), device=dev, dtype=torch.uint8)
-        self.tv_tgt = torch.zeros((B, g.T, model.n_tv), device=dev, dtype=torch.float32)
-        self.phn_tgt = torch.zeros((B, g.T), device=dev, dtype=torch.int64)
+        if self.kind == "pr":
+            self.labels = torch.full(tuple(batch["phoneme_labels"].shape), -100, device=dev, dtype=torch.int32)
+            self.state_lens = torch.zeros(B, device=dev, dtype=torch.int32)
+            self.target_lens = torch.zeros(B, device=dev, dtype=torch.int32)
+        else:
+            self.tv_tgt = torch.zeros((B, g.T, model.n_tv), device=dev, dtype=torch.float32)
+            self.phn_tgt = torch.zeros((B, g.T), device=dev, dtype=torch.int64)
         self.salt = torch.zeros(2, device=dev, dtype=torch.int32)
         self._salt_ring = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(4)]
         self._salt_events = [None] * 4
@@ -88,7 +98,7 @@ class GraphedAPTAIStep:
         # one eager step first: allocates every persistent scratch buffer, loads the code objects and sets the kernel
         # attributes outside of stream capture
         model.zero_grad(set_to_none=True)
-        model(0, **batch)["loss"].backward()
+        (model(**batch) if self.kind == "pr" else model(0, **batch))["loss"].backward()
         model.zero_grad(set_to_none=True)
         self._capture()
 
@@ -99,6 +109,8 @@ class GraphedAPTAIStep:
         10.7 ms/step against 10.3 with the batch resident (pageable copies, which block the host until the GPU has drained:
         34 ms/step)."""
         cfg, g = self.cfg, self.g
+        if self.kind == "pr":
+            return self._set_batch_pr(batch)
         lens_cpu = batch["audio_lengths"].detach().cpu().long()
         fl = hostlogic.feat_extract_output_lengths(lens_cpu, cfg.conv_kernel, cfg.conv_stride).clamp(min=1, max=g.T)
         self.frame_lens_cpu = fl
@@ -121,6 +133,25 @@ class GraphedAPTAIStep:
         self.lens_i32.copy_(fl.to(torch.int32))
         self.tv_tgt.copy_(torch.stack(tracks, dim=-1).float())
         self.phn_tgt.copy_(batch["phn_frames_49hz"])
+
+    def _set_batch_pr(self, batch: Dict[str, torch.Tensor]) -> None:
+        """Wav2Vec2_PR batch (input_values, input_lengths, phoneme_labels with -100 padding, models/w2v2_pr.py:40-70).  The label
+        block may be narrower than the one the graphs were captured with (padded with -100), never wider."""
+        cfg, g = self.cfg, self.g
+        lens_cpu = batch["input_lengths"].detach().cpu().long().reshape(-1)
+        sl = hostlogic.feat_extract_output_lengths(lens_cpu, cfg.conv_kernel, cfg.conv_stride)
+        self.frame_lens_cpu = sl.clamp(min=1, max=g.T)
+        lab = batch["phoneme_labels"]
+        if lab.shape[0] != self.labels.shape[0] or lab.shape[1] > self.labels.shape[1]:
+            raise ValueError(f"label block {tuple(lab.shape)} does not fit the captured {tuple(self.labels.shape)}")
+        dev = self.dev
+        self.audio.copy_(batch["input_values"].float(), non_blocking=True)
+        self.lens_i32.copy_(self.frame_lens_cpu.to(torch.int32), non_blocking=True)
+        self.state_lens.copy_(sl.to(torch.int32), non_blocking=True)
+        self.target_lens.copy_(hostlogic.ctc_target_lengths(lab).to(torch.int32), non_blocking=True)
+        if lab.shape[1] < self.labels.shape[1]:
+            self.labels.fill_(-100)
+        self.labels[:, :lab.shape[1]].copy_(lab.to(torch.int32), non_blocking=True)
 
     def _host_stage(self):
         ring = getattr(self, "_stage_ring", None)
@@ -204,7 +235,7 @@ class GraphedAPTAIStep:
             if embed is not None and cfg.apply_spec_augment and cfg.mask_time_prob > 0:
                 ops.spec_augment_mask(self.lens_i32, g.B, g.T, cfg.mask_time_prob, cfg.mask_time_length, cfg.mask_time_min_masks,
                                       _seed(seed, 77), out=self.spec)        # fresh spans on every replay (salted seed)
-            feats = w._conv_forward(self.audio, g, save=False)[0]
+            feats, self.sv_conv = w._conv_forward(self.audio, g, save=self.train_conv)
             (h,), self.s_front = self.front.fwd(feats, self.fparams, True)
         self.X = [h]
 
@@ -221,21 +252,32 @@ class GraphedAPTAIStep:
             self.X.append(y)
 
         # -- tail: [final LN] + heads forward + loss + heads backward + [final LN backward]
-        self.hparams = [model.tv_head[2].weight, model.tv_head[2].bias, model.phn_head[2].weight, model.phn_head[2].bias]
-        self.st_heads = SimpleNamespace(g=g, p_tv=model.tv_head[0].p, p_ph=model.phn_head[0].p, seed=_seed(seed, 999),
-                                        taps=model.tv_lowpass.taps(), tv_tgt=self.tv_tgt, phn_tgt=self.phn_tgt, w_mse=0.5, w_ce=0.5)
-        # data parallel: the loss backward inside the tail graph reads the global valid counts / world from this static buffer
-        self.loss_norm = getattr(model, "dp_loss_norm", None)
-        if self.loss_norm is not None:
-            self.st_heads.norm_scalars = self.loss_norm.buffer(self.dev)
         self.fin = _FinalLNImpl(cfg, g) if cfg.do_stable_layer_norm else None
+        self.loss_norm = None
+        if self.kind == "pr":
+            self.hparams = [model.pr_head.weight, model.pr_head.bias]
+            self.st_heads = SimpleNamespace(g=g, p_final=model.dropout.p, seed=_seed(seed, 777), targets=self.labels,
+                                            state_lens=self.state_lens, target_lens=self.target_lens, blank=getattr(cfg, "blank", 0),
+                                            reduction=cfg.ctc_loss_reduction, zero_infinity=cfg.ctc_zero_infinity)
+        else:
+            self.hparams = [model.tv_head[2].weight, model.tv_head[2].bias, model.phn_head[2].weight, model.phn_head[2].bias]
+            self.st_heads = SimpleNamespace(g=g, p_tv=model.tv_head[0].p, p_ph=model.phn_head[0].p, seed=_seed(seed, 999),
+                                            taps=model.tv_lowpass.taps(), tv_tgt=self.tv_tgt, phn_tgt=self.phn_tgt, w_mse=0.5, w_ce=0.5)
+            # data parallel: the loss backward inside the tail graph reads the global valid counts / world from this static buffer
+            self.loss_norm = getattr(model, "dp_loss_norm", None)
+            if self.loss_norm is not None:
+                self.st_heads.norm_scalars = self.loss_norm.buffer(self.dev)
         self.g_tail = mk()
         with torch.cuda.graph(self.g_tail, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
             hl = self.X[L]
             if self.fin is not None:
                 (hl,), s_fin = self.fin.fwd(hl, [w.encoder.layer_norm.weight, w.encoder.layer_norm.bias], True)
-            self.outs, s_heads = heads_fwd(hl, *self.hparams, self.st_heads)
-            dh, *hgrads = heads_bwd(s_heads, self.st_heads, None)
+            if self.kind == "pr":
+                self.outs, s_heads = pr_head_fwd(hl, *self.hparams, self.st_heads)
+                dh, *hgrads = pr_head_bwd(s_heads, self.st_heads, None)
+            else:
+                self.outs, s_heads = heads_fwd(hl, *self.hparams, self.st_heads)
+                dh, *hgrads = heads_bwd(s_heads, self.st_heads, None)
             fin_grads = []
             if self.fin is not None:
                 dh, fin_grads = self.fin.bwd(s_fin, (dh,), True)
@@ -261,10 +303,13 @@ class GraphedAPTAIStep:
         # -- front backward
         self.g_front_bwd = mk()
         with torch.cuda.graph(self.g_front_bwd, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
-            _, fg = self.front.bwd(self.s_front, (self.dX[0],), False)
+            dfeats, fg = self.front.bwd(self.s_front, (self.dX[0],), self.train_conv)
+            conv_grads = w._conv_backward(self.sv_conv, g, dfeats.contiguous()) if self.train_conv else []
         for p, gt in zip(self.fparams, fg):
             if p is not None and gt is not None:
                 self.grads[p] = gt
+        for p, gt in zip(w._conv_params(), conv_grads):
+            self.grads[p] = gt
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ one optimiser step
@@ -315,6 +360,11 @@ class GraphedAPTAIStep:
                                        f"contiguous={p.grad.is_contiguous()} (parameter: {p.dtype} {tuple(p.shape)})")
             self._checked = True
         self.opt.step()
+        if self.kind == "pr":
+            loss, logits, log_probs, hd = self.outs
+            g, V = self.g, self.hparams[0].shape[0]
+            return {"loss": loss, "phoneme_logits": logits.view(g.B, g.Tp, -1)[:, :g.T, :V], "log_probs": log_probs,
+                    "hidden_states": hd.view(g.B, g.Tp, -1)[:, :g.T]}
         loss, mse, ce, tvs, pred, _ = self.outs
         return {"loss": loss, "mse_loss": mse, "ce_loss": ce, "tvs_pred": tvs, "phn_fc_pred": pred}
 

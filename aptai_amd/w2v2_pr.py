@@ -17,43 +17,53 @@ from . import hostlogic, ops
 from .wav2vec2 import Wav2Vec2Model, _round_up, _seed
 
 
+def pr_head_fwd(h, w, b, st):
+    """dropout -> Linear(H, V) -> log_softmax -> CTC (models/w2v2_pr.py:54-81).  Returns ((loss, logits, log_probs, hd), saved)."""
+    g, M, H = st.g, st.g.M, h.shape[1]
+    dev = h.device
+    V = w.shape[0]
+    Np = _round_up(V, 64)
+    hd = ops.dropout(h, st.p_final, st.seed) if st.p_final > 0 else h
+    wp = torch.zeros((Np, H), device=dev, dtype=torch.bfloat16)
+    ops.cast_bf16(w.detach(), wp[:V])
+    bp = torch.zeros(Np, device=dev, dtype=torch.float32)
+    bp[:V] = b.detach()
+    logits = ops.gemm(hd, wp, M, Np, H, bias=bp, out_f32=True)
+    loss, nll, lp, alpha = ops.ctc_fwd(logits, Np, g.Tp, st.targets, st.state_lens, st.target_lens, g.B, g.T, V,
+                                       blank=st.blank, reduction=st.reduction, zero_infinity=st.zero_infinity)
+    return (loss.reshape(()), logits, lp, hd), SimpleNamespace(hd=hd, wp=wp, logits=logits, alpha=alpha, nll=nll, V=V, Np=Np)
+
+
+def pr_head_bwd(s, st, gloss):
+    """Fused CTC gradient -> (dh, dW, db) of the head; gloss = dLoss (None = 1)."""
+    g, M, H = st.g, st.g.M, s.hd.shape[1]
+    gl = torch.ones(1, device=s.hd.device, dtype=torch.float32) if gloss is None else gloss.float().reshape(1).contiguous()
+    dlog = ops.ctc_bwd(s.logits, s.Np, g.Tp, st.targets, st.state_lens, st.target_lens, g.B, g.T, s.V, s.alpha, s.nll, gl,
+                       blank=st.blank, reduction=st.reduction, zero_infinity=st.zero_infinity, ldd=s.Np)
+    dh = ops.gemm(dlog, s.wp, M, H, s.Np, b_kmajor=True)
+    sk = max(1, min(16, M // 1024))
+    dw = ops.gemm(dlog, s.hd, s.Np, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk)
+    db = ops.colsum(dlog, M, s.Np)
+    if st.p_final > 0:
+        dh = ops.dropout(dh, st.p_final, st.seed)
+    return dh, dw[:s.V], db[:s.V]
+
+
 class _CtcHeadFn(torch.autograd.Function):
-    """dropout -> Linear(H, V) -> log_softmax -> CTC (models/w2v2_pr.py:54-81) with the fused CTC gradient."""
+    """pr_head_fwd / pr_head_bwd behind autograd (the eager drop-in path)."""
 
     @staticmethod
     def forward(ctx, h, w, b, st):
-        g, M, H = st.g, st.g.M, h.shape[1]
-        dev = h.device
-        V = w.shape[0]
-        Np = _round_up(V, 64)
-        hd = ops.dropout(h, st.p_final, st.seed) if st.p_final > 0 else h
-        wp = torch.zeros((Np, H), device=dev, dtype=torch.bfloat16)
-        ops.cast_bf16(w.detach(), wp[:V])
-        bp = torch.zeros(Np, device=dev, dtype=torch.float32)
-        bp[:V] = b.detach()
-        logits = ops.gemm(hd, wp, M, Np, H, bias=bp, out_f32=True)
-        loss, nll, lp, alpha = ops.ctc_fwd(logits, Np, g.Tp, st.targets, st.state_lens, st.target_lens, g.B, g.T, V,
-                                           blank=st.blank, reduction=st.reduction, zero_infinity=st.zero_infinity)
-        ctx.st = st
-        ctx.saved = SimpleNamespace(hd=hd, wp=wp, logits=logits, alpha=alpha, nll=nll, V=V, Np=Np)
-        ctx.mark_non_differentiable(logits, lp, hd)
-        return loss.reshape(()), logits, lp, hd
+        outs, saved = pr_head_fwd(h, w, b, st)
+        ctx.st, ctx.saved = st, saved
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
 
     @staticmethod
     def backward(ctx, gloss, *_):
-        st, s = ctx.st, ctx.saved
-        g, M, H = st.g, st.g.M, s.hd.shape[1]
-        gl = gloss.float().reshape(1).contiguous()
-        dlog = ops.ctc_bwd(s.logits, s.Np, g.Tp, st.targets, st.state_lens, st.target_lens, g.B, g.T, s.V, s.alpha, s.nll, gl,
-                           blank=st.blank, reduction=st.reduction, zero_infinity=st.zero_infinity, ldd=s.Np)
-        dh = ops.gemm(dlog, s.wp, M, H, s.Np, b_kmajor=True)
-        sk = max(1, min(16, M // 1024))
-        dw = ops.gemm(dlog, s.hd, s.Np, H, M, a_kmajor=True, b_kmajor=True, out_f32=True, split_k=sk)
-        db = ops.colsum(dlog, M, s.Np)
-        if st.p_final > 0:
-            dh = ops.dropout(dh, st.p_final, st.seed)
+        dh, dw, db = pr_head_bwd(ctx.saved, ctx.st, gloss)
         ctx.saved = None
-        return dh, dw[:s.V], db[:s.V], None
+        return dh, dw, db, None
 
 
 class Wav2Vec2_PR(nn.Module):

@@ -400,7 +400,7 @@ def main():
         model.dp_loss_norm = GlobalLossNorm()
 
     runner = None
-    use_graph = (not args.eager) and wl == "aptai"
+    use_graph = (not args.eager) and wl in ("aptai", "pr")
     if use_graph:
         from aptai_amd.graphed import GraphedAPTAIStep
         capture_error = None

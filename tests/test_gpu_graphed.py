@@ -131,3 +131,62 @@ def test_graphed_step_takes_host_batches():
     assert len(set(round(v, 4) for v in losses["eager"])) > 1                  # the batches differ
     for a, b in zip(losses["eager"], losses["graph"]):
         assert abs(a - b) <= 2e-3 * abs(a), losses
+
+
+def test_graphed_pr_step_with_trainable_conv_stack_matches_eager():
+    """Wav2Vec2_PR fine-tuning (everything trainable incl. the 7-layer feature encoder, CTC head) through the same segment
+    graphs: with the stochastic regularisers off, losses and updated parameters follow the eager autograd loop over several
+    optimiser steps, a second batch with a narrower label block goes through set_batch, and a wider one is refused."""
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.graphed import GraphedAPTAIStep
+    from oracle import synth
+    from test_gpu_ctc_pr import _build_pr
+    cfg = W2V2Config.base(num_hidden_layers=2, hidden_dropout=0., activation_dropout=0., attention_dropout=0.,
+                          feat_proj_dropout=0., final_dropout=0., layerdrop=0., apply_spec_augment=False, vocab_size=40,
+                          ctc_loss_reduction="mean", ctc_zero_infinity=True)
+    sd = synth.make_state_dict(synth.pr_param_shapes(cfg), 0)
+    g = torch.Generator().manual_seed(5)
+
+    def mk_batch(seed, width):
+        sb = synth.synth_aptai_batch(cfg, 2, 16000, seed=seed)
+        lab = torch.full((2, width), -100, dtype=torch.int64)
+        for b in range(2):
+            n = int(torch.randint(5, width + 1, (1,), generator=g))
+            lab[b, :n] = torch.randint(1, 40, (n,), generator=g)
+        return {"input_values": sb["audio_inputs"].cuda(), "input_lengths": sb["audio_lengths"].reshape(-1).cuda(), "phoneme_labels": lab.cuda()}
+    batches = [mk_batch(3, 12), mk_batch(4, 9)]
+    losses, finals = {}, {}
+    for mode in ("eager", "graph"):
+        model = _build_pr(cfg, sd)
+        model.train()
+        assert any(p.requires_grad for p in model.wav2vec2.feature_extractor.parameters())
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+        ls = []
+        if mode == "eager":
+            for i in range(4):
+                opt.zero_grad(set_to_none=True)
+                out = model(**batches[i % 2])
+                out["loss"].backward()
+                opt.step()
+                ls.append(out["loss"].item())
+        else:
+            runner = GraphedAPTAIStep(model, opt, batches[0])
+            for i in range(4):
+                out = runner.step(batches[i % 2])
+                ls.append(out["loss"].item())
+            assert out["phoneme_logits"].shape == (2, 49, 40)
+            wide = dict(batches[0], phoneme_labels=torch.full((2, 20), 3, dtype=torch.int64).cuda())
+            with pytest.raises(ValueError):
+                runner.step(wide)
+            runner.close()
+        losses[mode] = ls
+        finals[mode] = {n: p.detach().float().cpu().clone() for n, p in model.named_parameters()}
+    for a, b in zip(losses["eager"], losses["graph"]):
+        assert abs(a - b) <= 2e-3 * abs(a), (losses["eager"], losses["graph"])
+    moved = 0
+    for n in finals["eager"]:
+        d = (finals["eager"][n] - finals["graph"][n]).abs().max().item()
+        assert d <= 2e-4, (n, d)
+        moved += int((finals["eager"][n] - sd[n].float()).abs().max().item() > 0)
+    assert moved > 20                                                    # conv stack, encoder and head were all updated
