@@ -137,7 +137,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, **kw) -> torc
     d = GemmDesc()
     out, _ws_keep = _gemm_desc(d, a, b, M, N, K, **kw)
     pr = _probe
-    if pr is not None and pr.key == (bool(d.a_kmajor), bool(d.b_kmajor), bool(d.out_f32)):
+    if pr is not None and pr.key == (bool(d.a_kmajor), bool(d.b_kmajor), bool(d.out_f32)) and not torch.cuda.is_current_stream_capturing():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _lib.check(_lib.lib().aptai_gemm_bf16(ctypes.byref(d), c_void_p(_stream())), "aptai_gemm_bf16")
@@ -164,7 +164,7 @@ def gemm_grouped(problems) -> list:
         flops += 2.0 * M * N * K
     pr = _probe
     d0 = descs[0]
-    if pr is not None and pr.key == (bool(d0.a_kmajor), bool(d0.b_kmajor), bool(d0.out_f32)):
+    if pr is not None and pr.key == (bool(d0.a_kmajor), bool(d0.b_kmajor), bool(d0.out_f32)) and not torch.cuda.is_current_stream_capturing():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _lib.check(_lib.lib().aptai_gemm_bf16_grouped(descs, len(problems), c_void_p(_stream())), "aptai_gemm_bf16_grouped")
