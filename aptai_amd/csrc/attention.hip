@@ -39,6 +39,7 @@ struct AttnArgs {
     bf16_t* dqkv;
     int skip_pad_q;
     int stagger;                    // experiment: s_sleep units (64 clocks) per wave-slot index at kernel start
+    int xcd_remap;
     int q_prescaled;                // the Q third of qkv already carries scale * log2(e) (QKV GEMM epilogue): scores arrive in the exp2 domain
 };
 
@@ -130,6 +131,20 @@ __device__ __forceinline__ bool attn_keep(uint32_t pair, int key, uint32_t s0, u
 
 // ================================================================================== forward
 // grid (Tp/128, heads, B), 256 threads; wave w: queries q0 = qt*128 + w*32 .. +31
+// Block -> (tile, head, utterance).  Workgroups are dealt round-robin over the 8 XCDs in launch order, so the Tp/128 tiles of one
+// (utterance, head) - which all read the same K / V (forward, dQ) or Q / dO (dK/dV) - would land on as many different L2s.
+// The remap gives every XCD a contiguous run of (utterance, head) groups with all their tiles (speed only: any dispatch order is
+// correct).  APTAI_ATTN_XCD_REMAP=0 keeps the launch order (A/B).
+__device__ __forceinline__ void attn_block(const AttnArgs& a, int& tile, int& hd, int& b) {
+    const int nt = gridDim.x, total = nt * gridDim.y * gridDim.z;
+    int L = blockIdx.x + nt * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (a.xcd_remap && (total & 7) == 0) L = (L & 7) * (total >> 3) + (L >> 3);
+    tile = L % nt;
+    const int grp = L / nt;
+    hd = grp % (int)gridDim.y;
+    b = grp / (int)gridDim.y;
+}
+
 // The per-BLOCK cost matters as much as the tile loop at T ~ 500 (8 key tiles): the epilogue goes through LDS so that every
 // store instruction writes whole 128-byte row segments (a lane owns one QUERY, so storing from the accumulators directly is
 // 8 or 16 bytes per lane at a row stride: 32-64 distinct lines per instruction, 32 instructions per wave).
@@ -159,8 +174,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[FWD_SMEM];
     if (DROP) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int b = blockIdx.z, hd = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    int tile_x, hd, b;
+    attn_block(a, tile_x, hd, b);
+    const int q0 = tile_x * 128 + wave * 32;
     int len = a.lens[b];
     len = len < 1 ? 1 : (len > a.Tp ? a.Tp : len);
     const int ntiles = (len + 63) >> 6;
@@ -364,8 +380,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     float* sL = (float*)(smem + STAGE_BYTES);           // [0,32) lse2, [32,64) delta, [64,96) dropout row hash of the tile's queries
     if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int b = blockIdx.z, hd = blockIdx.y;
-    const int kb0 = blockIdx.x * 128;
+    int tile_x, hd, b;
+    attn_block(a, tile_x, hd, b);
+    const int kb0 = tile_x * 128;
     const int key0 = kb0 + wave * 32;
     int len = a.lens[b];
     len = len < 1 ? 1 : (len > a.Tp ? a.Tp : len);
@@ -526,8 +543,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
     float* sDel = (float*)(smem + STAGE_BYTES);                             // delta of the block's 128 queries
     if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int b = blockIdx.z, hd = blockIdx.y;
-    const int qb0 = blockIdx.x * 128;
+    int tile_x, hd, b;
+    attn_block(a, tile_x, hd, b);
+    const int qb0 = tile_x * 128;
     const int q = qb0 + wave * 32 + (lane & 31);
     int len = a.lens[b];
     len = len < 1 ? 1 : (len > a.Tp ? a.Tp : len);
@@ -655,6 +673,8 @@ int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens
     a.salt = aptai_seed_salt(stream);
     static const int stagger = getenv("APTAI_ATTN_STAGGER") ? atoi(getenv("APTAI_ATTN_STAGGER")) : 0;
     a.stagger = stagger;
+    static const int remap = getenv("APTAI_ATTN_XCD_REMAP") ? atoi(getenv("APTAI_ATTN_XCD_REMAP")) : 1;
+    a.xcd_remap = remap;
     return APTAI_OK;
 }
 
