@@ -1,6 +1,7 @@
 """Fold rocprofv3 --pmc counter_collection CSVs (one directory per pass) into a per-kernel table of mean counter values."""
 import csv
 import glob
+import os
 import json
 import re
 import sys
@@ -10,7 +11,8 @@ from collections import defaultdict
 def main():
     out = defaultdict(lambda: defaultdict(list))
     for d in sys.argv[1:]:
-        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+        for f in files[-1:]:                                   # the newest run only (the directories accumulate runs)
             for r in csv.DictReader(open(f)):
                 m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
                 name = m.group(1) if m else r["Kernel_Name"][:60]

@@ -9,6 +9,7 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p "$O"
+# (each pass writes into a fresh directory: rocprofv3 adds files next to older ones)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$O/stats.log" 2>&1
 echo "[refresh] stats done"

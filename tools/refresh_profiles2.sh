@@ -6,6 +6,7 @@ TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/profiles_$TAG
 mkdir -p "$O"
+# (each pass writes into a fresh directory: rocprofv3 adds files next to older ones)
 cd /tmp && export TMPDIR=/tmp
 for wl in force pr; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${wl}_stats" -- python3 "$R/bench.py" --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > "$O/${wl}_stats.log" 2>&1
