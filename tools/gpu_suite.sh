@@ -1,7 +1,8 @@
 #!/bin/bash
+# Full GPU pass on the box: pytest -m gpu, then the three bench workloads (gpurun --timeout 1200 -- bash tools/gpu_suite.sh)
 set -eo pipefail
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/r2g
+O=$R/gpurun_out/gpu_suite
 mkdir -p "$O"
 cd "$R"
 timeout -k 10 1100 python -m pytest tests -m gpu -q -x > "$O/pytest.log" 2>&1 || { grep -E "FAILED|Error|assert|error" "$O/pytest.log" | head -60; exit 1; }
