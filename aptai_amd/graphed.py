@@ -209,9 +209,13 @@ class GraphedAPTAIStep:
         w._refresh_layer_copies(force=True)                  # copies valid before the first replay whoever refreshes them later
         w._cache_mode = "build"
         torch.cuda.synchronize()
+        if not self.train_conv:
+            w._conv_weights()                                # frozen feature encoder: its bf16 weight copies are built once, here
+            torch.cuda.synchronize()
         self.g_prep = mk()
         with torch.cuda.graph(self.g_prep, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
-            w._conv_weights()
+            if self.train_conv:
+                w._conv_weights()
             if not getattr(self.opt, "publishes_copies", False):     # else the optimiser kernel refreshes the copies itself
                 w._refresh_layer_copies(force=True)
             self.lw = [w._layer_weights(i, g.M) for i in range(L)]
