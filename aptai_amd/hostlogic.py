@@ -24,10 +24,29 @@ def conv_out_length(n, kernel: int, stride: int):
 
 
 def feat_extract_output_lengths(n, conv_kernel: Sequence[int], conv_stride: Sequence[int]):
-    """HF:997-1016 ``_get_feat_extract_output_lengths`` (no adapter). Exact integer arithmetic."""
+    """HF:997-1016 ``_get_feat_extract_output_lengths`` (no adapter). Exact integer arithmetic.
+
+    Device tensors take the composed form: ``floor((floor(a / p) + q) / r) == floor((a + p q) / (p r))`` for integers with
+    p, r > 0, so the seven ``floor((n - k) / s) + 1`` steps fold into ONE ``floor((n + c) / d)`` (c, d from the loop below:
+    c = -80, d = 320 for wav2vec2) - two tiny launches instead of 21 on the step's dependency chain, bit-identical for every
+    integer n (tests/test_cpu_host.py sweeps it against the step-by-step form)."""
+    if isinstance(n, torch.Tensor) and n.is_cuda and not n.is_floating_point():
+        c, d = 0, 1
+        for k, s in zip(conv_kernel, conv_stride):
+            c += d * (s - k)
+            d *= s
+        return torch.div(n + c, d, rounding_mode="floor")
     for k, s in zip(conv_kernel, conv_stride):
         n = conv_out_length(n, k, s)
     return n
+
+
+def _composed_length_constants(conv_kernel: Sequence[int], conv_stride: Sequence[int]):
+    c, d = 0, 1
+    for k, s in zip(conv_kernel, conv_stride):
+        c += d * (s - k)
+        d *= s
+    return c, d
 
 
 def conv_layer_lengths(n_samples: int, conv_kernel: Sequence[int], conv_stride: Sequence[int]) -> List[int]:

@@ -227,3 +227,16 @@ def test_resample_and_one_second_crop():
     first = [i for i, (a, b) in enumerate(spans) if a <= t0 < b][0]
     last = [i for i, (a, b) in enumerate(spans) if a < t1 <= b][0]
     assert item["phoneme_label"] == [1, 2, 3, 4][first:last + 1]
+
+
+def test_composed_frame_length_formula_equals_the_step_by_step_one():
+    """hostlogic.feat_extract_output_lengths folds the seven floor((n - k) / s) + 1 steps (HF:997-1016) into one floor((n + c) / d)
+    for device tensors: identical for every integer, negative intermediate lengths included."""
+    from aptai_amd import hostlogic as h
+    n = np.arange(-3000, 500000, dtype=np.int64)
+    for ck, cs in (((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)), ((7, 5, 3), (3, 2, 2)), ((4, 4), (4, 3)), ((10,), (5,))):
+        c, d = h._composed_length_constants(ck, cs)
+        assert np.array_equal(h.feat_extract_output_lengths(n, ck, cs), np.floor_divide(n + c, d)), (ck, cs)
+    assert h._composed_length_constants((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)) == (-80, 320)
+    t = torch.tensor([159999, 160000, 400, 399, 0], dtype=torch.int64)
+    assert h.feat_extract_output_lengths(t, (10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)).tolist() == [499, 499, 1, 0, -1]
