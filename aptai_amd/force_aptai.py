@@ -28,114 +28,127 @@ from .wav2vec2 import _seed
 _NPHN = 60
 
 
+def force_heads_fwd(ac, st, P):
+    """Everything of Force_APTAI.forward after the encoder, fp32 on the device (csrc/force.hip, lstm.hip, ctc.hip).  Returns
+    ((loss, tv_loss, align_loss, tvs, frame_phns, att_log, att_out, hout, align), saved) - shared by the autograd path
+    (_ForceHeadsFn) and the hipGraph runner (graphed.GraphedForceStep)."""
+    (fl_w, fl_b, emb_w, q_w, q_b, k_w, k_b, ln_w, ln_b, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, l0_w, l0_b, l3_w,
+     l3_b) = P
+    g = st.g
+    B, Tp, T, M, H = g.B, g.Tp, g.T, g.M, ac.shape[1]
+    dev = ac.device
+    s = SimpleNamespace()
+    s.phn = ops.embed_pe_fwd(st.ids, emb_w, st.pe, _NPHN, st.p_hid, _seed(st.seed, 1))                    # [B*60][128]
+    fh = ops.linear_f32(ac, fl_w, fl_b, rows=M)                                                           # [M][128]
+    s.fhd = ops.dropout_f32(fh, st.p_hid, _seed(st.seed, 2))
+    s.cat = torch.empty((M, 256), device=dev, dtype=torch.float32)
+    q = s.cat[:, 128:]
+    ops.linear_f32(s.fhd, q_w, q_b, out=q, ldc=256)
+    s.k = ops.linear_f32(s.phn, k_w, k_b)                                                                  # [B*60][128]
+    raw = ops.sgemm(q, 256, 1, s.k, 1, 128, Tp, _NPHN, 128, batch=B, bsa=Tp * 256, bsb=_NPHN * 128, bsc=Tp * _NPHN)
+    # forward-sum (CTC) input rows [blank = -1 | att_log | 0], written by the same kernel
+    s.pad = torch.empty((M, 64), device=dev, dtype=torch.float32)
+    s.energy, s.att, s.att_log, s.align = ops.xattn_softmax_fwd(raw, st.ids, B, Tp, _NPHN, fs_rows=s.pad)
+    ops.sgemm(s.att, _NPHN, 1, s.k, 128, 1, Tp, 128, _NPHN, out=s.cat, ldc=256, batch=B, bsa=Tp * _NPHN, bsb=_NPHN * 128,
+              bsc=Tp * 256)
+    s.att_out, s.lm, s.lr = ops.layernorm_f32_fwd(s.cat, ln_w, ln_b)
+    s.wih = torch.cat([wih0, wih1]).contiguous()                                                          # [2048][256]
+    bsum = torch.cat([bih0 + bhh0, bih1 + bhh1]).contiguous()
+    xproj = ops.linear_f32(s.att_out, s.wih, bsum)                                                         # [M][2048]
+    s.whh = torch.stack([whh0, whh1]).contiguous()                                                         # [2][1024][256]
+    s.hout, s.gates, s.cst = ops.lstm_fwd(xproj, s.whh, st.rnn_lens, B, Tp, T)
+    h1 = ops.linear_f32(s.hout, l0_w, l0_b)
+    s.h1a = ops.tanh_dropout_fwd(h1, st.p_rnn, _seed(st.seed, 3))
+    tv_raw = ops.linear_f32(s.h1a, l3_w, l3_b)                                                             # [M][9]
+    n_tv = l3_w.shape[0]
+    s.tvs = torch.empty((B, T, n_tv), device=dev, dtype=torch.float32)
+    ops.lowpass_fir(tv_raw, n_tv, Tp, st.taps, s.tvs, n_tv, T, B, T, T, n_tv, n_tv)
+    s.dummy_logits = torch.zeros((M, 1), device=dev, dtype=torch.float32)
+    s.dummy_phn = torch.zeros((B, T), device=dev, dtype=torch.int64)
+    s.sc, _ = ops.aptai_loss_fwd(s.tvs, st.tv_tgt, s.dummy_logits, 1, Tp, s.dummy_phn, B, T, n_tv, 1, 1.0, 0.0, want_pred=False)
+    # forward-sum (CTC) alignment loss on [blank=-1 | att_log]
+    s.fs_loss, s.nll, _, s.alpha = ops.ctc_fwd(s.pad, 64, Tp, st.fs_targets, st.frame_lens, st.text_lens, B, T, _NPHN + 1,
+                                               blank=0, reduction="mean", zero_infinity=True, vocab_sizes_i32=st.vocab_sizes,
+                                               want_log_probs=False)
+    tv_loss = s.sc[1].clone()
+    align_loss = s.fs_loss.reshape(()).clone()
+    loss = 0.4 * tv_loss + 0.6 * align_loss
+    frame_phns = ops.gather_alignment(st.ids, s.align, st.frame_lens, B, Tp, _NPHN)
+    return (loss, tv_loss, align_loss, s.tvs, frame_phns, s.att_log, s.att_out, s.hout, s.align), s
+
+
+def force_heads_bwd(s, st, P, ac, gloss=None):
+    """Gradients of the 21 head parameters (order of P) for dLoss = gloss (None = 1)."""
+    (fl_w, fl_b, emb_w, q_w, q_b, k_w, k_b, ln_w, ln_b, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, l0_w, l0_b, l3_w,
+     l3_b) = P
+    g = st.g
+    B, Tp, T, M, H = g.B, g.Tp, g.T, g.M, ac.shape[1]
+    dev = ac.device
+    n_tv = l3_w.shape[0]
+    gl = torch.ones(1, device=ac.device, dtype=torch.float32) if gloss is None else gloss.float().reshape(1)
+    # ---- TV branch
+    norm = getattr(st, "norm_scalars", None)             # data parallel: global valid TV count / world (dp.GlobalLossNorm)
+    d_tvs, _ = ops.aptai_loss_bwd(s.tvs, st.tv_tgt, s.dummy_logits, 1, Tp, s.dummy_phn, B, T, n_tv, 1, 1.0, 0.0,
+                                  norm() if norm is not None else s.sc, (0.4 * gl).contiguous(), ldd=8)
+    d_tvraw = torch.empty((M, n_tv), device=dev, dtype=torch.float32)
+    ops.lowpass_fir(d_tvs, n_tv, T, st.taps, d_tvraw, n_tv, Tp, B, T, Tp, n_tv, n_tv)
+    dl3_w = ops.sgemm(d_tvraw, 1, n_tv, s.h1a, 256, 1, n_tv, 256, M)
+    dl3_b = ops.colsum_f32(d_tvraw, M, n_tv)
+    dh1a = ops.sgemm(d_tvraw, n_tv, 1, l3_w, 256, 1, M, 256, n_tv)
+    dh1 = ops.tanh_dropout_bwd(s.h1a, dh1a, st.p_rnn, _seed(st.seed, 3))
+    dl0_w = ops.sgemm(dh1, 1, 256, s.hout, 512, 1, 256, 512, M)
+    dl0_b = ops.colsum_f32(dh1, M, 256)
+    dhout = ops.sgemm(dh1, 256, 1, l0_w, 512, 1, M, 512, 256)
+    dgates = ops.lstm_bwd(dhout, s.whh, st.rnn_lens, s.gates, s.cst, B, Tp, T)                              # [M][2048]
+    dwih = ops.sgemm(dgates, 1, 2048, s.att_out, 256, 1, 2048, 256, M)
+    dbg = ops.colsum_f32(dgates, M, 2048)
+    # dW_hh[dir] = sum_t dgates[t][dir]^T h_prev[t][dir]  (h_prev = previous VISITED frame: t-1 forward, t+1 reverse;
+    # the rows in between utterances hold zeros in hout / dgates, so one shifted GEMM over all rows is exact)
+    dwhh0 = ops.sgemm(dgates[1:], 1, 2048, s.hout, 512, 1, 1024, 256, M - 1)
+    dwhh1 = ops.sgemm(dgates[:, 1024:], 1, 2048, s.hout[1:, 256:], 512, 1, 1024, 256, M - 1)
+    datt_out = ops.sgemm(dgates, 2048, 1, s.wih, 256, 1, M, 256, 2048)
+    dcat, dln_w, dln_b = ops.layernorm_f32_bwd(datt_out, s.cat, s.lm, s.lr, ln_w)
+    # ---- cross attention
+    d_att = ops.sgemm(dcat, 256, 1, s.k, 1, 128, Tp, _NPHN, 128, batch=B, bsa=Tp * 256, bsb=_NPHN * 128, bsc=Tp * _NPHN)
+    dk = ops.sgemm(s.att, 1, _NPHN, dcat, 256, 1, _NPHN, 128, Tp, batch=B, bsa=Tp * _NPHN, bsb=Tp * 256, bsc=_NPHN * 128)
+    dpad = ops.ctc_bwd(s.pad, 64, Tp, st.fs_targets, st.frame_lens, st.text_lens, B, T, _NPHN + 1, s.alpha, s.nll,
+                       (0.6 * gl).contiguous(), blank=0, reduction="mean", zero_infinity=True, vocab_sizes_i32=st.vocab_sizes,
+                       ldd=64, out_dtype=torch.float32)
+    d_raw = ops.xattn_softmax_bwd(s.att, s.att_log, d_att, dpad[:, 1:], ld_dattlog=64)     # columns 1..60 of the 64-float rows, in place
+    dq = dcat[:, 128:].contiguous()
+    ops.sgemm(d_raw, _NPHN, 1, s.k, 128, 1, Tp, 128, _NPHN, out=dq, ldc=128, accumulate=True, batch=B, bsa=Tp * _NPHN,
+              bsb=_NPHN * 128, bsc=Tp * 128)
+    ops.sgemm(d_raw, 1, _NPHN, s.cat[:, 128:], 256, 1, _NPHN, 128, Tp, out=dk, ldc=128, accumulate=True, batch=B,
+              bsa=Tp * _NPHN, bsb=Tp * 256, bsc=_NPHN * 128)
+    dq_w = ops.sgemm(dq, 1, 128, s.fhd, 128, 1, 128, 128, M)
+    dq_b = ops.colsum_f32(dq, M, 128)
+    dfhd = ops.sgemm(dq, 128, 1, q_w, 128, 1, M, 128, 128)
+    dk_w = ops.sgemm(dk, 1, 128, s.phn, 128, 1, 128, 128, B * _NPHN)
+    dk_b = ops.colsum_f32(dk, B * _NPHN, 128)
+    dphn = ops.sgemm(dk, 128, 1, k_w, 128, 1, B * _NPHN, 128, 128)
+    demb = ops.embed_bwd(st.ids, dphn, emb_w.shape[0], st.p_hid, _seed(st.seed, 1))
+    dfh = ops.dropout_f32(dfhd, st.p_hid, _seed(st.seed, 2))
+    dfl_wT = ops.sgemm(ac, 1, H, dfh, 128, 1, H, 128, M)                                                    # [H][128]
+    dfl_b = ops.colsum_f32(dfh, M, 128)
+    return (dfl_wT.t().contiguous(), dfl_b, demb, dq_w, dq_b, dk_w, dk_b, dln_w, dln_b,
+            dwih[:1024], dwhh0, dbg[:1024], dbg[:1024], dwih[1024:], dwhh1, dbg[1024:], dbg[1024:], dl0_w, dl0_b, dl3_w, dl3_b)
+
+
 class _ForceHeadsFn(torch.autograd.Function):
-    """Everything of Force_APTAI.forward after the encoder, fp32 on the device; see csrc/force.hip."""
+    """force_heads_fwd / force_heads_bwd behind autograd (the eager drop-in path)."""
 
     @staticmethod
     def forward(ctx, ac, st, *P):
-        (fl_w, fl_b, emb_w, q_w, q_b, k_w, k_b, ln_w, ln_b, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, l0_w, l0_b, l3_w,
-         l3_b) = P
-        g = st.g
-        B, Tp, T, M, H = g.B, g.Tp, g.T, g.M, ac.shape[1]
-        dev = ac.device
-        s = SimpleNamespace()
-        s.phn = ops.embed_pe_fwd(st.ids, emb_w, st.pe, _NPHN, st.p_hid, _seed(st.seed, 1))                    # [B*60][128]
-        fh = ops.linear_f32(ac, fl_w, fl_b, rows=M)                                                           # [M][128]
-        s.fhd = ops.dropout_f32(fh, st.p_hid, _seed(st.seed, 2))
-        s.cat = torch.empty((M, 256), device=dev, dtype=torch.float32)
-        q = s.cat[:, 128:]
-        ops.linear_f32(s.fhd, q_w, q_b, out=q, ldc=256)
-        s.k = ops.linear_f32(s.phn, k_w, k_b)                                                                  # [B*60][128]
-        raw = ops.sgemm(q, 256, 1, s.k, 1, 128, Tp, _NPHN, 128, batch=B, bsa=Tp * 256, bsb=_NPHN * 128, bsc=Tp * _NPHN)
-        # forward-sum (CTC) input rows [blank = -1 | att_log | 0], written by the same kernel
-        s.pad = torch.empty((M, 64), device=dev, dtype=torch.float32)
-        s.energy, s.att, s.att_log, s.align = ops.xattn_softmax_fwd(raw, st.ids, B, Tp, _NPHN, fs_rows=s.pad)
-        ops.sgemm(s.att, _NPHN, 1, s.k, 128, 1, Tp, 128, _NPHN, out=s.cat, ldc=256, batch=B, bsa=Tp * _NPHN, bsb=_NPHN * 128,
-                  bsc=Tp * 256)
-        s.att_out, s.lm, s.lr = ops.layernorm_f32_fwd(s.cat, ln_w, ln_b)
-        s.wih = torch.cat([wih0, wih1]).contiguous()                                                          # [2048][256]
-        bsum = torch.cat([bih0 + bhh0, bih1 + bhh1]).contiguous()
-        xproj = ops.linear_f32(s.att_out, s.wih, bsum)                                                         # [M][2048]
-        s.whh = torch.stack([whh0, whh1]).contiguous()                                                         # [2][1024][256]
-        s.hout, s.gates, s.cst = ops.lstm_fwd(xproj, s.whh, st.rnn_lens, B, Tp, T)
-        h1 = ops.linear_f32(s.hout, l0_w, l0_b)
-        s.h1a = ops.tanh_dropout_fwd(h1, st.p_rnn, _seed(st.seed, 3))
-        tv_raw = ops.linear_f32(s.h1a, l3_w, l3_b)                                                             # [M][9]
-        n_tv = l3_w.shape[0]
-        s.tvs = torch.empty((B, T, n_tv), device=dev, dtype=torch.float32)
-        ops.lowpass_fir(tv_raw, n_tv, Tp, st.taps, s.tvs, n_tv, T, B, T, T, n_tv, n_tv)
-        s.dummy_logits = torch.zeros((M, 1), device=dev, dtype=torch.float32)
-        s.dummy_phn = torch.zeros((B, T), device=dev, dtype=torch.int64)
-        s.sc, _ = ops.aptai_loss_fwd(s.tvs, st.tv_tgt, s.dummy_logits, 1, Tp, s.dummy_phn, B, T, n_tv, 1, 1.0, 0.0, want_pred=False)
-        # forward-sum (CTC) alignment loss on [blank=-1 | att_log]
-        s.fs_loss, s.nll, _, s.alpha = ops.ctc_fwd(s.pad, 64, Tp, st.fs_targets, st.frame_lens, st.text_lens, B, T, _NPHN + 1,
-                                                   blank=0, reduction="mean", zero_infinity=True, vocab_sizes_i32=st.vocab_sizes,
-                                                   want_log_probs=False)
-        tv_loss = s.sc[1].clone()
-        align_loss = s.fs_loss.reshape(()).clone()
-        loss = 0.4 * tv_loss + 0.6 * align_loss
-        frame_phns = ops.gather_alignment(st.ids, s.align, st.frame_lens, B, Tp, _NPHN)
+        outs, s = force_heads_fwd(ac, st, P)
         ctx.st, ctx.saved, ctx.P, ctx.ac = st, s, P, ac
-        ctx.mark_non_differentiable(tv_loss, align_loss, s.tvs, frame_phns, s.att_log, s.att_out, s.hout, s.align)
-        return loss, tv_loss, align_loss, s.tvs, frame_phns, s.att_log, s.att_out, s.hout, s.align
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
 
     @staticmethod
     def backward(ctx, gloss, *_):
-        st, s, P, ac = ctx.st, ctx.saved, ctx.P, ctx.ac
-        (fl_w, fl_b, emb_w, q_w, q_b, k_w, k_b, ln_w, ln_b, wih0, whh0, bih0, bhh0, wih1, whh1, bih1, bhh1, l0_w, l0_b, l3_w,
-         l3_b) = P
-        g = st.g
-        B, Tp, T, M, H = g.B, g.Tp, g.T, g.M, ac.shape[1]
-        dev = ac.device
-        n_tv = l3_w.shape[0]
-        gl = gloss.float().reshape(1)
-        # ---- TV branch
-        norm = getattr(st, "norm_scalars", None)             # data parallel: global valid TV count / world (dp.GlobalLossNorm)
-        d_tvs, _ = ops.aptai_loss_bwd(s.tvs, st.tv_tgt, s.dummy_logits, 1, Tp, s.dummy_phn, B, T, n_tv, 1, 1.0, 0.0,
-                                      norm() if norm is not None else s.sc, (0.4 * gl).contiguous(), ldd=8)
-        d_tvraw = torch.empty((M, n_tv), device=dev, dtype=torch.float32)
-        ops.lowpass_fir(d_tvs, n_tv, T, st.taps, d_tvraw, n_tv, Tp, B, T, Tp, n_tv, n_tv)
-        dl3_w = ops.sgemm(d_tvraw, 1, n_tv, s.h1a, 256, 1, n_tv, 256, M)
-        dl3_b = ops.colsum_f32(d_tvraw, M, n_tv)
-        dh1a = ops.sgemm(d_tvraw, n_tv, 1, l3_w, 256, 1, M, 256, n_tv)
-        dh1 = ops.tanh_dropout_bwd(s.h1a, dh1a, st.p_rnn, _seed(st.seed, 3))
-        dl0_w = ops.sgemm(dh1, 1, 256, s.hout, 512, 1, 256, 512, M)
-        dl0_b = ops.colsum_f32(dh1, M, 256)
-        dhout = ops.sgemm(dh1, 256, 1, l0_w, 512, 1, M, 512, 256)
-        dgates = ops.lstm_bwd(dhout, s.whh, st.rnn_lens, s.gates, s.cst, B, Tp, T)                              # [M][2048]
-        dwih = ops.sgemm(dgates, 1, 2048, s.att_out, 256, 1, 2048, 256, M)
-        dbg = ops.colsum_f32(dgates, M, 2048)
-        # dW_hh[dir] = sum_t dgates[t][dir]^T h_prev[t][dir]  (h_prev = previous VISITED frame: t-1 forward, t+1 reverse;
-        # the rows in between utterances hold zeros in hout / dgates, so one shifted GEMM over all rows is exact)
-        dwhh0 = ops.sgemm(dgates[1:], 1, 2048, s.hout, 512, 1, 1024, 256, M - 1)
-        dwhh1 = ops.sgemm(dgates[:, 1024:], 1, 2048, s.hout[1:, 256:], 512, 1, 1024, 256, M - 1)
-        datt_out = ops.sgemm(dgates, 2048, 1, s.wih, 256, 1, M, 256, 2048)
-        dcat, dln_w, dln_b = ops.layernorm_f32_bwd(datt_out, s.cat, s.lm, s.lr, ln_w)
-        # ---- cross attention
-        d_att = ops.sgemm(dcat, 256, 1, s.k, 1, 128, Tp, _NPHN, 128, batch=B, bsa=Tp * 256, bsb=_NPHN * 128, bsc=Tp * _NPHN)
-        dk = ops.sgemm(s.att, 1, _NPHN, dcat, 256, 1, _NPHN, 128, Tp, batch=B, bsa=Tp * _NPHN, bsb=Tp * 256, bsc=_NPHN * 128)
-        dpad = ops.ctc_bwd(s.pad, 64, Tp, st.fs_targets, st.frame_lens, st.text_lens, B, T, _NPHN + 1, s.alpha, s.nll,
-                           (0.6 * gl).contiguous(), blank=0, reduction="mean", zero_infinity=True, vocab_sizes_i32=st.vocab_sizes,
-                           ldd=64, out_dtype=torch.float32)
-        d_raw = ops.xattn_softmax_bwd(s.att, s.att_log, d_att, dpad[:, 1:], ld_dattlog=64)     # columns 1..60 of the 64-float rows, in place
-        dq = dcat[:, 128:].contiguous()
-        ops.sgemm(d_raw, _NPHN, 1, s.k, 128, 1, Tp, 128, _NPHN, out=dq, ldc=128, accumulate=True, batch=B, bsa=Tp * _NPHN,
-                  bsb=_NPHN * 128, bsc=Tp * 128)
-        ops.sgemm(d_raw, 1, _NPHN, s.cat[:, 128:], 256, 1, _NPHN, 128, Tp, out=dk, ldc=128, accumulate=True, batch=B,
-                  bsa=Tp * _NPHN, bsb=Tp * 256, bsc=_NPHN * 128)
-        dq_w = ops.sgemm(dq, 1, 128, s.fhd, 128, 1, 128, 128, M)
-        dq_b = ops.colsum_f32(dq, M, 128)
-        dfhd = ops.sgemm(dq, 128, 1, q_w, 128, 1, M, 128, 128)
-        dk_w = ops.sgemm(dk, 1, 128, s.phn, 128, 1, 128, 128, B * _NPHN)
-        dk_b = ops.colsum_f32(dk, B * _NPHN, 128)
-        dphn = ops.sgemm(dk, 128, 1, k_w, 128, 1, B * _NPHN, 128, 128)
-        demb = ops.embed_bwd(st.ids, dphn, emb_w.shape[0], st.p_hid, _seed(st.seed, 1))
-        dfh = ops.dropout_f32(dfhd, st.p_hid, _seed(st.seed, 2))
-        dfl_wT = ops.sgemm(ac, 1, H, dfh, 128, 1, H, 128, M)                                                    # [H][128]
-        dfl_b = ops.colsum_f32(dfh, M, 128)
+        grads = force_heads_bwd(ctx.saved, ctx.st, ctx.P, ctx.ac, gloss)
         ctx.saved = None
-        return (None, None, dfl_wT.t().contiguous(), dfl_b, demb, dq_w, dq_b, dk_w, dk_b, dln_w, dln_b,
-                dwih[:1024], dwhh0, dbg[:1024], dbg[:1024], dwih[1024:], dwhh1, dbg[1024:], dbg[1024:], dl0_w, dl0_b, dl3_w, dl3_b)
+        return (None, None) + tuple(grads)
 
 
 class Force_APTAI(nn.Module):
@@ -265,19 +278,10 @@ class Force_APTAI(nn.Module):
             t.record_stream(cur)
         return enc
 
-    def _run(self, audio_inputs, audio_lengths, tv_targets=None, phn_pred_list=None, _ac_override=None, _prefetch_next=None):
-        """Encoder (inference) -> decode -> heads.  Nothing in here synchronises host and device: the best-path decode, the
-        phoneme slots, every length vector and the alignment read-out stay on the device; `_lists` makes the Python lists the
-        reference returns with one round of transfers at the very end."""
+    def _heads_state(self, g, ids, nlen, frame_lens, tv_targets, step):
+        """(st, P) of force_heads_fwd / force_heads_bwd for one encoded batch (all device tensors; no synchronisation)."""
         pr = self.w2v2_pr
-        enc = self._take_prefetched(audio_inputs, audio_lengths) if phn_pred_list is None else None
-        if enc is None:
-            enc = self._encode(audio_inputs, audio_lengths, phn_pred_list)
-        if _prefetch_next is not None:                                 # the NEXT batch's encoder pass goes out before this batch's heads
-            self.prefetch(*_prefetch_next)
-        g, ids, nlen, frame_lens = enc.g, enc.ids, enc.nlen, enc.frame_lens
-        dev = enc.ac.device
-        ac = enc.ac if _ac_override is None else _ac_override          # test hook: heads on given embeddings
+        dev = ids.device
         tr = self.training
         n_tv = self.rnn.linear[3].weight.shape[0]
         if tv_targets is None:
@@ -287,7 +291,7 @@ class Force_APTAI(nn.Module):
         rnn_lens = consts["full_T"](g.T) if g.B == 1 else frame_lens
         st = SimpleNamespace(g=g, ids=ids, pe=self.pe_phn.pe.reshape(_NPHN, -1).contiguous(), taps=self.tv_lowpass.taps(),
                              p_hid=self.hidden_drop if tr else 0.0, p_rnn=self.rnn_drop if tr else 0.0,
-                             seed=_seed(pr.wav2vec2.base_seed, enc.step, 4242),
+                             seed=_seed(pr.wav2vec2.base_seed, step, 4242),
                              tv_tgt=tv_targets.contiguous(), fs_targets=consts["fs_targets"], frame_lens=frame_lens, rnn_lens=rnn_lens,
                              text_lens=nlen, vocab_sizes=nlen + 1)
         if getattr(self, "dp_loss_norm", None) is not None and tr:
@@ -301,6 +305,22 @@ class Force_APTAI(nn.Module):
              lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0, lstm.weight_ih_l0_reverse,
              lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse, self.rnn.linear[0].weight,
              self.rnn.linear[0].bias, self.rnn.linear[3].weight, self.rnn.linear[3].bias)
+        return st, P
+
+    def _run(self, audio_inputs, audio_lengths, tv_targets=None, phn_pred_list=None, _ac_override=None, _prefetch_next=None):
+        """Encoder (inference) -> decode -> heads.  Nothing in here synchronises host and device: the best-path decode, the
+        phoneme slots, every length vector and the alignment read-out stay on the device; `_lists` makes the Python lists the
+        reference returns with one round of transfers at the very end."""
+        pr = self.w2v2_pr
+        enc = self._take_prefetched(audio_inputs, audio_lengths) if phn_pred_list is None else None
+        if enc is None:
+            enc = self._encode(audio_inputs, audio_lengths, phn_pred_list)
+        if _prefetch_next is not None:                                 # the NEXT batch's encoder pass goes out before this batch's heads
+            self.prefetch(*_prefetch_next)
+        g, ids, nlen, frame_lens = enc.g, enc.ids, enc.nlen, enc.frame_lens
+        dev = enc.ac.device
+        ac = enc.ac if _ac_override is None else _ac_override          # test hook: heads on given embeddings
+        st, P = self._heads_state(g, ids, nlen, frame_lens, tv_targets, enc.step)
         res = _ForceHeadsFn.apply(ac, st, *P)
         return res, g, (ids, nlen, frame_lens, phn_pred_list)
 

@@ -408,3 +408,147 @@ class GraphedAPTAIStep:
                 self._cap_stream = None
         except Exception:               # noqa: BLE001 - interpreter shutdown
             pass
+
+
+class GraphedForceStep:
+    """hipGraph runner for the Force_APTAI train step (models/force_aptai.py:80-178, train/train_force_aptai.py:392-531): TWO graphs,
+
+        encoder (frozen recogniser in inference mode + best-path decode, on a side stream)  |  heads forward + loss + heads backward
+
+    replayed one batch apart: while the heads of batch n replay on the caller's stream, the encoder of batch n+1 (handed to
+    step() as `next_batch`, or the same batch again) replays on the side stream.  Same kernels and the same two Python functions
+    (force_heads_fwd / force_heads_bwd) as the eager autograd path; dropout draws fresh masks per replay through the per-stream
+    salt; nothing synchronises host and device (`lists()` makes the Python lists of the reference's return value on demand).
+    The optimiser step is issued eagerly after the heads graph."""
+
+    def __init__(self, model, optimizer, batch: Dict[str, torch.Tensor]):
+        from .force_aptai import Force_APTAI, force_heads_bwd, force_heads_fwd
+        assert isinstance(model, Force_APTAI) and model.training, "a Force_APTAI model in train() mode"
+        if getattr(model, "dp_loss_norm", None) is not None:
+            raise NotImplementedError("GraphedForceStep is single-process (the eager step carries the DP loss normalisation)")
+        self.model, self.opt = model, optimizer
+        dev = next(model.parameters()).device
+        self.dev = dev
+        self.audio = batch["audio_inputs"].float().contiguous().clone()
+        self.lengths = batch["audio_lengths"].clone()
+        self._tracks = [k for k in batch if k not in ("audio_inputs", "audio_lengths", "phn_frames_49hz", "phoneme_labels")]
+        w = model.w2v2_pr.wav2vec2
+        B, S = self.audio.shape
+        self.g = w._geometry(B, S)
+        g = self.g
+        n_tv = model.rnn.linear[3].weight.shape[0]
+        self.tv_tgt = torch.zeros((B, g.T, n_tv), device=dev, dtype=torch.float32)
+        self.salt = torch.zeros(2, device=dev, dtype=torch.int32)
+        self._salt_ring = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(4)]
+        self._salt_events = [None] * 4
+        self._salt_turn = 0
+        self._salt_gen = np.random.RandomState(0xF0CE + w.base_seed)
+        self._cap_stream = torch.cuda.Stream(device=dev)
+        self._enc_stream = torch.cuda.Stream(device=dev)
+        _bind_salt(self._cap_stream.cuda_stream, self.salt)
+        # one eager step: scratch buffers, code objects, weight copies
+        model.zero_grad(set_to_none=True)
+        model(0, **batch)["loss"].backward()
+        model.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        # ---- encoder graph (side stream): static inputs -> enc.{ac, ids, nlen, frame_lens}
+        self.g_enc = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_enc, pool=pool, stream=self._enc_stream, capture_error_mode=_CAPTURE_MODE):
+            self.enc = model._encode(self.audio, self.lengths)
+        # ---- heads graph: its own copies of the encoder outputs (the next encoder replay overwrites enc.*)
+        e = self.enc
+        self.h_ac, self.h_ids, self.h_nlen, self.h_fl = (torch.empty_like(t) for t in (e.ac, e.ids, e.nlen, e.frame_lens))
+        self.st, self.P = model._heads_state(g, self.h_ids, self.h_nlen, self.h_fl, self.tv_tgt, 0xF0)
+        self.g_heads = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_heads, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
+            self.st.vocab_sizes = self.h_nlen + 1             # derived from a static input: recomputed on every replay
+            self.outs, saved = force_heads_fwd(self.h_ac, self.st, self.P)
+            self.pgrads = force_heads_bwd(saved, self.st, self.P, self.h_ac, None)
+        torch.cuda.synchronize()
+        self._have_enc = False
+        self._enc_done = None
+        self._last = batch
+        self.set_batch(batch)
+
+    # ------------------------------------------------------------------ inputs of the HEADS (targets) and of the encoder
+    def set_batch(self, batch: Dict[str, torch.Tensor]) -> None:
+        """Targets of the batch whose heads run in the next step()."""
+        self.tv_tgt.copy_(torch.stack([batch[k] for k in self._tracks], dim=-1).float(), non_blocking=True)
+
+    def _launch_encoder(self, batch: Dict[str, torch.Tensor]) -> None:
+        cur = torch.cuda.current_stream(self.dev)
+        es = self._enc_stream
+        es.wait_stream(cur)                                   # the batch tensors, and the previous copies out of enc.*
+        with torch.cuda.stream(es):
+            self.audio.copy_(batch["audio_inputs"].float(), non_blocking=True)
+            self.lengths.copy_(batch["audio_lengths"], non_blocking=True)
+            self.g_enc.replay()
+            self._enc_done = torch.cuda.Event()
+            self._enc_done.record(es)
+        self.model.w2v2_pr.wav2vec2._step += 1
+        self._have_enc = True
+
+    def _salt_step(self):
+        slot = self._salt_turn
+        self._salt_turn = (slot + 1) % len(self._salt_ring)
+        if self._salt_events[slot] is not None:
+            self._salt_events[slot].synchronize()
+        self._salt_ring[slot].copy_(torch.from_numpy(self._salt_gen.randint(-2 ** 31, 2 ** 31 - 1, size=2).astype(np.int32)))
+        self.salt.copy_(self._salt_ring[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._salt_events[slot] = ev
+
+    # ------------------------------------------------------------------ one optimiser step
+    def step(self, batch: Optional[Dict[str, torch.Tensor]] = None, next_batch: Optional[Dict[str, torch.Tensor]] = None):
+        """Heads of `batch` (default: the batch given last) + optimiser step; the encoder pass of `next_batch` (default: `batch`
+        again) goes out on the side stream first.  The very first call encodes `batch` inline."""
+        if batch is not None:
+            self.set_batch(batch)
+            self._last = batch
+        batch = batch if batch is not None else self._last
+        cur = torch.cuda.current_stream(self.dev)
+        if not self._have_enc:
+            self._launch_encoder(batch)
+        cur.wait_event(self._enc_done)
+        e = self.enc
+        self.h_ac.copy_(e.ac, non_blocking=True); self.h_ids.copy_(e.ids, non_blocking=True)
+        self.h_nlen.copy_(e.nlen, non_blocking=True); self.h_fl.copy_(e.frame_lens, non_blocking=True)
+        self._launch_encoder(next_batch if next_batch is not None else batch)      # waits for the four copies above
+        self._salt_step()
+        self.g_heads.replay()
+        for p, gt in zip(self.P, self.pgrads):
+            if p.requires_grad:
+                p.grad = gt                                    # (bias_ih / bias_hh of a direction share one gradient buffer)
+        self.opt.step()
+        loss, tv_loss, align_loss, tvs, frame_phns = self.outs[:5]
+        return {"loss": loss, "tv_loss": tv_loss, "align_loss": align_loss, "tvs_pred": tvs, "frame_phns": frame_phns,
+                "ids": self.h_ids, "n_ids": self.h_nlen, "frame_lens": self.h_fl}
+
+    def lists(self, out) -> Dict[str, list]:
+        """The Python lists of Force_APTAI.forward (pred_frame_phns, pred_ctc_phn_seq) for a step() result: the only transfers."""
+        given, fl, n, table = self.model._lists((out["ids"], out["n_ids"], out["frame_lens"], None))
+        fp = out["frame_phns"].cpu().numpy()
+        return {"pred_frame_phns": [fp[b, :fl[b]].tolist() for b in range(self.g.B)], "pred_ctc_phn_seq": given}
+
+    def close(self):
+        if getattr(self, "_cap_stream", None) is not None:
+            torch.cuda.synchronize(self.dev)
+            _unbind_salt(self._cap_stream.cuda_stream)
+            self._cap_stream = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_cap_stream", None) is not None:
+                _unbind_salt(self._cap_stream.cuda_stream)
+                self._cap_stream = None
+        except Exception:               # noqa: BLE001 - interpreter shutdown
+            pass

@@ -400,14 +400,17 @@ def main():
         model.dp_loss_norm = GlobalLossNorm()
 
     runner = None
-    use_graph = (not args.eager) and wl in ("aptai", "pr")
+    use_graph = (not args.eager) and (wl in ("aptai", "pr") or (wl == "force" and world == 1 and not args.no_pipeline))
     if use_graph:
-        from aptai_amd.graphed import GraphedAPTAIStep
+        from aptai_amd.graphed import GraphedAPTAIStep, GraphedForceStep
         capture_error = None
         try:
             if reducer is not None:
                 reducer.remove()             # gradients are reduced explicitly after the captured backward
-            runner = GraphedAPTAIStep(model, opt, batch, reducer=reducer)
+            if wl == "force":                # encoder graph (side stream, one batch ahead) + heads graph
+                runner = GraphedForceStep(model, opt, batch)
+            else:
+                runner = GraphedAPTAIStep(model, opt, batch, reducer=reducer)
         except Exception as e:               # noqa: BLE001 - multi-rank only: same kernels through the eager loop, and say so
             if world == 1:
                 raise

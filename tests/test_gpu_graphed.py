@@ -190,3 +190,76 @@ def test_graphed_pr_step_with_trainable_conv_stack_matches_eager():
         assert d <= 2e-4, (n, d)
         moved += int((finals["eager"][n] - sd[n].float()).abs().max().item() > 0)
     assert moved > 20                                                    # conv stack, encoder and head were all updated
+
+
+def test_graphed_force_step_matches_eager_and_varies_with_dropout():
+    """GraphedForceStep: encoder graph (side stream, one batch ahead) + heads graph.  With the head dropouts at 0 the losses and
+    the updated head parameters follow the eager loop over alternating batches; with the reference's dropouts on, replays of
+    one batch draw different masks (the per-stream salt), and lists() returns the reference's Python lists."""
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.graphed import GraphedForceStep
+    from aptai_amd.optim import Adam
+    from oracle import synth
+    from test_gpu_force import _build, load_golden
+    z, meta = load_golden("force_aptai_1x2s")
+    pr_cfg = W2V2Config.from_any(meta["pr_cfg"])
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, meta["vocab_len"]), meta["seed"])
+    B, S = 4, 32000
+    batches = []
+    for seed in (8, 9):
+        bt = {k: v.cuda() for k, v in synth.synth_aptai_batch(pr_cfg, B, S, seed=seed, n_phn=40).items()}
+        bt["phoneme_labels"] = torch.zeros(B, 4, dtype=torch.int32).cuda()
+        batches.append(bt)
+
+    def fresh(drop):
+        model, _ = _build(meta, sd)
+        model.train()
+        if not drop:
+            model.hidden_drop = 0.0
+            model.rnn_drop = 0.0
+        with torch.no_grad():                                   # the random-weight recogniser must decode 1..59 phonemes
+            blank = model.w2v2_pr._blank()
+            for _ in range(60):
+                n = [len(l) for bt in batches for l in model.w2v2_pr._decode(model.w2v2_pr._logits_eval(bt["audio_inputs"], bt["audio_lengths"].reshape(-1)[:, None])[0])]
+                if max(n) < 60 and min(n) >= 1:
+                    break
+                model.w2v2_pr.pr_head.bias[blank] += 0.25 if max(n) >= 60 else -0.25
+            else:
+                pytest.skip("no blank bias gives 1..59 phonemes on both batches")
+        params = [p for p in model.parameters() if p.requires_grad]
+        return model, params, Adam(params, lr=1e-4)
+
+    losses, finals = {}, {}
+    for mode in ("eager", "graph"):
+        model, params, opt = fresh(False)
+        ls = []
+        if mode == "eager":
+            for i in range(4):
+                opt.zero_grad(set_to_none=True)
+                out = model(0, **batches[i % 2])
+                out["loss"].backward()
+                opt.step()
+                ls.append(out["loss"].item())
+        else:
+            runner = GraphedForceStep(model, opt, batches[0])
+            for i in range(4):
+                out = runner.step(batches[i % 2], next_batch=batches[(i + 1) % 2])
+                ls.append(out["loss"].item())
+            lists = runner.lists(out)
+            assert len(lists["pred_frame_phns"]) == B and len(lists["pred_ctc_phn_seq"]) == B
+            assert out["tvs_pred"].shape[0] == B and out["tvs_pred"].shape[2] == 9
+            runner.close()
+        losses[mode] = ls
+        finals[mode] = {n: p.detach().float().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+    for a, b in zip(losses["eager"], losses["graph"]):
+        assert abs(a - b) <= 1e-4 * abs(a), (losses["eager"], losses["graph"])
+    for n in finals["eager"]:
+        d = (finals["eager"][n] - finals["graph"][n]).abs().max().item()
+        assert d <= 2e-5, (n, d)                                       # fp32 heads, same kernels: atomics-level differences only
+    # dropout on: two replays of the same batch draw different masks
+    model, params, opt = fresh(True)
+    runner = GraphedForceStep(model, opt, batches[0])
+    a = runner.step(batches[0])["tvs_pred"].clone()
+    b = runner.step(batches[0])["tvs_pred"].clone()
+    runner.close()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
