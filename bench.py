@@ -534,7 +534,10 @@ def main():
                                       f"bucket average = {default_algo()}") if world > 1 else None,
                        "regularisers": "off" if args.no_regularisers else "HF defaults",
                        "optimizer": "Adam, fp32 state (torch fused)" if args.torch_adam else "Adam, fp32 state (aptai_adam_multi)",
-                       "execution": "hipGraph segments (aptai_amd.graphed)" if use_graph else "eager autograd loop",
+                       "execution": (("encoder hipGraph one batch ahead on a side stream + heads hipGraph (aptai_amd.graphed.GraphedForceStep)"
+                                      if wl == "force" else "hipGraph segments (aptai_amd.graphed)") if use_graph else
+                                     ("eager autograd loop, frozen-encoder pass one batch ahead on a side stream (Force_APTAI.prefetch)"
+                                      if (wl == "force" and not args.no_pipeline) else "eager autograd loop")),
                        "inputs": "pinned host batch copied in every step (PCIe-inclusive)" if args.host_batch else "resident in HBM"},
             "loss": round(loss, 5),
             "roofline": {"bound": "mfma", "kernel": "bf16 MFMA GEMM, NT layout (gemm_kernel / gemm192_kernel / gemm256_kernel <false,false,false>): every launch of the step",
