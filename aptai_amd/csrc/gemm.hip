@@ -580,6 +580,12 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = fmaf(v[r], alpha, bias8[r]);
         if (OUT_F32) {
+            if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder): += res32[m][n..n+7]
+                const float* R = (const float*)g.residual + (long)m * g.ldr + n;
+                const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+            }
             float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
             *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
             *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -1147,6 +1153,12 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
             for (int r = 0; r < 8; ++r) v[r] *= alpha;
         }
         if (OUT_F32) {
+            if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder): += res32[m][n..n+7]
+                const float* R = (const float*)g.residual + (long)m * g.ldr + n;
+                const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+            }
             float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
             *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
             *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -1193,6 +1205,10 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     if (d->b_kmajor) APTAI_REQUIRE(d->N >= 8, "aptai_gemm_bf16: K-major B needs N >= 8");
     if (d->flags & APTAI_EPI_BIAS) APTAI_REQUIRE(d->bias != nullptr, "aptai_gemm_bf16: EPI_BIAS without bias");
     if (d->flags & APTAI_EPI_RESIDUAL) APTAI_REQUIRE(d->residual != nullptr, "aptai_gemm_bf16: EPI_RESIDUAL without residual");
+    if (d->flags & APTAI_EPI_RESIDUAL_F32)
+        APTAI_REQUIRE(d->residual != nullptr && d->out_f32 && !(d->flags & APTAI_EPI_RESIDUAL) && d->split_k <= 1 && !d->accumulate &&
+                      (d->tile == 128 || d->tile == 64 || d->tile == 192),
+                      "aptai_gemm_bf16: EPI_RESIDUAL_F32 needs fp32 output, a residual, no split-K / accumulate and tile 64, 128 or 192");
     if (d->flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) APTAI_REQUIRE(d->aux != nullptr, "aptai_gemm_bf16: EPI_DGELU / EPI_MUL_AUX without aux");
     if (d->flags & APTAI_EPI_PRE_DGELU) APTAI_REQUIRE(d->out_pre != nullptr && (d->flags & APTAI_EPI_GELU), "aptai_gemm_bf16: EPI_PRE_DGELU needs EPI_GELU and out_pre");
 

@@ -9,6 +9,51 @@
 
 namespace {
 
+// fp32 residual stream of the inference-only encoder (Force_APTAI's frozen recogniser, opt-in): the row arrives in fp32 (the
+// GEMM before it added bias and residual in fp32) and leaves twice - bf16 for the next GEMM's A operand, fp32 for the next
+// residual add - so the residual path is never rounded to bf16.  Same statistics, same lane mapping as ln_fwd_kernel.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                         float* __restrict__ y32, long rows, float eps) {
+    constexpr int COLS = NCH * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gm[NCH][4], bt[NCH][4];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const f32x4 g4 = *(const f32x4*)(gamma + (j * 64 + lane) * 4);
+        const f32x4 b4 = *(const f32x4*)(beta + (j * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { gm[j][r] = g4[r]; bt[j][r] = b4[r]; }
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float* xr = x + row * COLS;
+        float v[NCH][4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const f32x4 p = *(const f32x4*)(xr + (j * 64 + lane) * 4);
+            v[j][0] = p[0]; v[j][1] = p[1]; v[j][2] = p[2]; v[j][3] = p[3];
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        const float mu = wave_sum(s) * (1.0f / COLS);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = v[j][r] - mu; q += d * d; }
+        const float rs = rsqrtf(wave_sum(q) * (1.0f / COLS) + eps);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (v[j][r] - mu) * rs * gm[j][r] + bt[j][r];
+            if (y) *(u32x2*)(y + row * COLS + (j * 64 + lane) * 4) = (u32x2){pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            if (y32) *(f32x4*)(y32 + row * COLS + (j * 64 + lane) * 4) = (f32x4){o[0], o[1], o[2], o[3]};
+        }
+    }
+}
+
 template <int NCH>   // cols = NCH * 256
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
@@ -210,6 +255,26 @@ extern "C" int64_t aptai_layernorm_bwd_workspace_bytes(int64_t rows, int64_t col
     long blocks = ceil_div(rows, 4);
     if (blocks > LN_BWD_MAX_BLOCKS) blocks = LN_BWD_MAX_BLOCKS;
     return blocks * 2 * cols * 4;
+}
+
+extern "C" int aptai_layernorm_fwd_f32in(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                                         int64_t rows, int64_t cols, float eps, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APTAI_REQUIRE(x && gamma && beta && (y_bf16 || y_f32), "aptai_layernorm_fwd_f32in: null pointer");
+    APTAI_REQUIRE(rows > 0, "aptai_layernorm_fwd_f32in: rows=%ld", (long)rows);
+    APTAI_REQUIRE(cols % 256 == 0 && cols >= 256 && cols <= 1024, "aptai_layernorm_fwd_f32in: cols=%ld (need 256..1024, %%256)", (long)cols);
+    long blocks = ceil_div(rows, 4);
+    if (blocks > 2048) blocks = 2048;
+#define LN_FWD32(NCH) APTAI_LAUNCH(ln_fwd_f32_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, (long)rows, eps)
+    switch (cols / 256) {
+        case 1: LN_FWD32(1); break;
+        case 2: LN_FWD32(2); break;
+        case 3: LN_FWD32(3); break;
+        default: LN_FWD32(4); break;
+    }
+#undef LN_FWD32
+    APTAI_CHECK_LAUNCH("ln_fwd_f32_kernel");
+    return APTAI_OK;
 }
 
 extern "C" int aptai_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd,

@@ -186,6 +186,9 @@ class Force_APTAI(nn.Module):
         self.tv_lowpass = LowPassFilterLayer(self.device, 10, 49, 9)
         for param in self.w2v2_pr.parameters():
             param.requires_grad = False
+        # the frozen recogniser only ever runs forward here: keep its residual stream in fp32 and hand the heads an fp32 last hidden
+        # state (+1.6 % step time, smaller bf16 noise band on the alignment indices; "bf16" restores the plain bf16 stream)
+        self.w2v2_pr.wav2vec2.set_encoder_precision("bf16_f32res")
         self._enc_stream = None        # side stream of prefetch()
         self._enc_graphs = {}          # batch shape -> captured encoder pass
         self._enc_seen = {}
@@ -210,7 +213,10 @@ class Force_APTAI(nn.Module):
                     padded.append(np.pad(np.asarray(lst, dtype=np.int64), (0, self.max_phn_seq_len - len(lst)), mode='constant'))
                 ids = torch.tensor(np.array(padded), dtype=torch.int32, device=dev)
                 nlen = torch.tensor([len(l) for l in phn_pred_list], dtype=torch.int32, device=dev)
-        return SimpleNamespace(g=out._geom, ac=out._flat_last, ids=ids, nlen=nlen, frame_lens=frame_lens, step=pr.wav2vec2._step)
+        # with the fp32 residual stream the heads read the UNROUNDED last hidden state (the fp32 GEMM takes either dtype)
+        ac = getattr(out, "_flat_last_f32", None)
+        return SimpleNamespace(g=out._geom, ac=ac if ac is not None else out._flat_last, ids=ids, nlen=nlen, frame_lens=frame_lens,
+                               step=pr.wav2vec2._step)
 
     def prefetch(self, audio_inputs, audio_lengths):
         """Run the frozen recogniser for a batch on a side stream NOW; the next forward / _run called with these same tensors
@@ -368,8 +374,9 @@ class Force_APTAI(nn.Module):
                 'pred_frame_phns': pred_frame_phns, 'pred_ctc_phn_seq': phn_pred_list}
 
     def set_encoder_precision(self, precision: str = "bf16"):
-        """"mxfp8": the frozen recogniser's transformer Linear layers run with MX block-scaled FP8 operands (BASELINE configs[4]);
-        the heads stay fp32.  See Wav2Vec2Model.set_encoder_precision."""
+        """"bf16_f32res" (default here): bf16 GEMMs, fp32 residual stream; "bf16": all-bf16 stream; "mxfp8": the frozen recogniser's
+        transformer Linear layers run with MX block-scaled FP8 operands (BASELINE configs[4]).  The heads stay fp32.  See
+        Wav2Vec2Model.set_encoder_precision."""
         self.w2v2_pr.wav2vec2.set_encoder_precision(precision)
         return self
 

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_DGELU, EPI_ALPHA, EPI_PRE_DGELU, EPI_MUL_AUX = 1, 2, 4, 8, 16, 32, 64, 128
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_DGELU, EPI_ALPHA, EPI_PRE_DGELU, EPI_MUL_AUX, EPI_RESIDUAL_F32 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 c_void_p, c_i64, c_int, c_float, c_u64 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
                                           ctypes.c_uint64)
@@ -73,7 +73,7 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
                a_kmajor=False, b_kmajor=False, out_f32=False, bias=None, gelu=False, residual=None, out_pre=None,
                dgelu_aux=None, alpha: Optional[float] = None, dropout_p: float = 0.0, seed: int = 0, split_k: int = 1,
                accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None, tile: int = 0,
-               ldaux=None, pre_dgelu: bool = False, mul_aux=None, colscale=None):
+               ldaux=None, pre_dgelu: bool = False, mul_aux=None, colscale=None, residual_f32=None):
     """Fills one aptai_gemm_desc in place; returns (out, workspace) - the caller keeps them alive across the launch."""
     _dev(a, b, out, bias, residual, out_pre, dgelu_aux, mul_aux)
     if out is None:
@@ -92,6 +92,10 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
     if residual is not None:
         flags |= EPI_RESIDUAL
         d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    if residual_f32 is not None:   # fp32 output += fp32 residual (the inference-only encoder's fp32 residual stream)
+        _dev(residual_f32)
+        flags |= EPI_RESIDUAL_F32
+        d.residual, d.ldr = residual_f32.data_ptr(), residual_f32.stride(0)
     if out_pre is not None:
         d.out_pre = out_pre.data_ptr()
     if dgelu_aux is not None:
@@ -250,6 +254,16 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dres=None, dropout_p=0.0, seed=0,
 
 # ----------------------------------------------------------------------------- attention
 ATTN_LOG2E = 1.4426950408889634
+
+
+def layernorm_fwd_f32in(x32, gamma, beta, eps, *, want_bf16=True, want_f32=True):
+    """nn.LayerNorm on an fp32 activation [rows][cols] -> (bf16 copy | None, fp32 copy | None) (aptai_layernorm_fwd_f32in)."""
+    _dev(x32, gamma, beta)
+    rows, cols = x32.shape
+    y = torch.empty((rows, cols), device=x32.device, dtype=torch.bfloat16) if want_bf16 else None
+    y32 = torch.empty((rows, cols), device=x32.device, dtype=torch.float32) if want_f32 else None
+    _lib.call("aptai_layernorm_fwd_f32in", x32.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(y), _ptr(y32), rows, cols, eps, _stream())
+    return y, y32
 
 
 def attention_qscale(H: int, heads: int) -> float:

@@ -164,6 +164,31 @@ class _LayerImpl:
         s.ln = (ln1w, ln1b, ln2w, ln2b)
         return (y,), (s if need else None)
 
+    def fwd_f32res(self, x, x32, params):
+        """Inference only, opt-in (set_encoder_precision("bf16_f32res")): the residual stream stays in fp32 - out-proj and FFN2
+        write fp32 and add the fp32 residual in their epilogues, LayerNorm reads fp32 and hands the next GEMM a bf16 copy and the
+        next residual add an fp32 one.  GEMM operands and attention stay bf16.  Returns (y_bf16 | None, y_f32)."""
+        cfg, g, w = self.cfg, self.g, self.w
+        M, H, I = g.M, cfg.hidden_size, cfg.intermediate_size
+        ln1w, ln1b, ln2w, ln2b = params[:4]
+        heads = cfg.num_attention_heads
+        qs = (H, ops.attention_qscale(H, heads))
+        if cfg.do_stable_layer_norm:                       # pre-LN (large): x32 is the un-normalised stream
+            n1, _ = ops.layernorm_fwd_f32in(x32, ln1w, ln1b, cfg.layer_norm_eps, want_f32=False)
+            qkv = ops.gemm(n1, w.wqkv, M, 3 * H, H, bias=w.bqkv, colscale=qs)
+            ctx, _ = ops.attention_fwd(qkv, self.lens, g.B, g.Tp, H, heads, save_lse=False, q_prescaled=True)
+            s1 = ops.gemm(ctx, w.wo, M, H, H, bias=w.bo, out_f32=True, residual_f32=x32, tile=128)
+            n2, _ = ops.layernorm_fwd_f32in(s1, ln2w, ln2b, cfg.layer_norm_eps, want_f32=False)
+            u = ops.gemm(n2, w.w1, M, I, H, bias=w.b1, gelu=True)
+            return None, ops.gemm(u, w.w2, M, H, I, bias=w.b2, out_f32=True, residual_f32=s1, tile=128)
+        qkv = ops.gemm(x, w.wqkv, M, 3 * H, H, bias=w.bqkv, colscale=qs)
+        ctx, _ = ops.attention_fwd(qkv, self.lens, g.B, g.Tp, H, heads, save_lse=False, q_prescaled=True)
+        s1 = ops.gemm(ctx, w.wo, M, H, H, bias=w.bo, out_f32=True, residual_f32=x32, tile=128)
+        n1, n1_32 = ops.layernorm_fwd_f32in(s1, ln1w, ln1b, cfg.layer_norm_eps)
+        u = ops.gemm(n1, w.w1, M, I, H, bias=w.b1, gelu=True)
+        s2 = ops.gemm(u, w.w2, M, H, I, bias=w.b2, out_f32=True, residual_f32=n1_32, tile=128)
+        return ops.layernorm_fwd_f32in(s2, ln2w, ln2b, cfg.layer_norm_eps)
+
     def _fwd_mxfp8(self, x, params, mx):
         """Inference-only forward with MX block-scaled FP8 operands in the four Linear layers (BASELINE configs[4]; csrc/mxgemm.hip):
         every GEMM input is quantised on the fly (E4M3 elements, E8M0 scale per 32 k), the frozen weights were quantised once;
@@ -531,8 +556,11 @@ class Wav2Vec2Model(nn.Module):
         """"bf16" (default) or "mxfp8": the latter runs the Linear layers of the transformer stack with OCP MXFP8 operands on the
         block-scaled matrix instruction - INFERENCE ONLY (eval mode, no gradients: the frozen recogniser inside Force_APTAI,
         BASELINE configs[4]); any forward that needs gradients keeps the bf16 kernels."""
-        if precision not in ("bf16", "mxfp8"):
-            raise ValueError("encoder precision must be 'bf16' or 'mxfp8'")
+        # "bf16_f32res": bf16 GEMM operands and attention, but the RESIDUAL STREAM of the transformer stack in fp32 (LayerNorm reads
+        # fp32, out-proj / FFN2 add the fp32 residual in their epilogues) and an fp32 last hidden state for the heads - inference
+        # only; shrinks the bf16 noise band of the integer outputs downstream (forced-alignment indices) at ~+10 % encoder time
+        if precision not in ("bf16", "mxfp8", "bf16_f32res"):
+            raise ValueError("encoder precision must be 'bf16', 'mxfp8' or 'bf16_f32res'")
         self._encoder_precision = precision
         return self
 
@@ -651,10 +679,14 @@ class Wav2Vec2Model(nn.Module):
     def _scratch(self, key, numel, dev):
         """Persistent zero-initialised bf16 scratch (the zero gap rows of the packed positional-conv operands are
         written once here and never again)."""
-        cur = self._scratch_bufs.get(key)
-        if cur is None or cur.numel() != numel or cur.device != dev:
+        # one buffer per (key, size): a buffer is NEVER replaced or freed while the model lives - captured hipGraphs (the
+        # graph runners, Force_APTAI.prefetch) hold its address, and a forward with another batch shape in between (validation
+        # at batch 1 between training epochs) used to swap it out from under them: the next replays read freed memory
+        full = (key, int(numel), str(dev))
+        cur = self._scratch_bufs.get(full)
+        if cur is None:
             cur = torch.zeros(numel, device=dev, dtype=torch.bfloat16)
-            self._scratch_bufs[key] = cur
+            self._scratch_bufs[full] = cur
         return cur
 
     # ------------------------------------------------------------------ geometry of one batch
@@ -855,6 +887,23 @@ class Wav2Vec2Model(nn.Module):
         # ---- transformer layers with LayerDrop (HF:694-707 / 767-780)
         self._refresh_layer_copies()
         hidden = []
+        if getattr(self, "_encoder_precision", "bf16") == "bf16_f32res" and not training and not torch.is_grad_enabled():
+            # fp32 residual stream (inference only, see set_encoder_precision)
+            h32 = h.float()
+            for i, layer in enumerate(self.encoder.layers):
+                hidden.append(h if h is not None else h32)
+                wt, _lin = self._layer_weights(i, g.M)
+                impl = _LayerImpl(cfg, g, lens_i32, wt, False, 0)
+                h, h32 = impl.fwd_f32res(h, h32, [layer.layer_norm.weight, layer.layer_norm.bias, layer.final_layer_norm.weight,
+                                                   layer.final_layer_norm.bias])
+            if cfg.do_stable_layer_norm:
+                h, h32 = ops.layernorm_fwd_f32in(h32, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias, cfg.layer_norm_eps)
+            hidden.append(h)
+            out = Wav2Vec2BaseModelOutput(last_hidden_state=h.view(B, g.Tp, -1)[:, :g.T], extract_features=None,
+                                          hidden_states=tuple(t.view(B, g.Tp, -1)[:, :g.T] for t in hidden) if output_hidden_states else None,
+                                          attentions=None)
+            out._geom, out._frame_lens, out._flat_last, out._flat_last_f32 = g, frame_lens, h, h32
+            return out
         for i, layer in enumerate(self.encoder.layers):
             hidden.append(h)
             skip = training and cfg.layerdrop > 0 and (float(torch.rand([], generator=self._layerdrop_gen)) < cfg.layerdrop)

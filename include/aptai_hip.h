@@ -54,7 +54,9 @@ enum {
     APTAI_EPI_DGELU = 16,    /* *= gelu'(aux[m*ldaux+n]) — backward of the FFN activation */
     APTAI_EPI_ALPHA = 32,
     APTAI_EPI_PRE_DGELU = 64, /* with EPI_GELU: out_pre receives dropmask/(1-p) * gelu'(pre-activation) instead of the pre-activation */
-    APTAI_EPI_MUL_AUX = 128   /* *= aux[m*ldaux+n] (bf16): the backward partner of EPI_PRE_DGELU */
+    APTAI_EPI_MUL_AUX = 128,  /* *= aux[m*ldaux+n] (bf16): the backward partner of EPI_PRE_DGELU */
+    APTAI_EPI_RESIDUAL_F32 = 256 /* fp32 output only (tile 64 / 128 / 192): += residual[m*ldr+n] read as FP32 - the residual stream of the
+                                  * inference-only encoder kept in fp32 (HF:594-601: hidden_states = attn_residual + hidden_states) */
 };
 
 typedef struct {
@@ -101,6 +103,10 @@ int aptai_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
                         int64_t rows, int64_t cols, float eps, int gelu_after, void* stream);
 /* dx = LN'(dy) [+ dres]; optional dx_drop = dropout-masked copy of dx (mask of (seed, element index), for the
  * branch that went through nn.Dropout, HF:591,628); dgamma/dbeta fp32 [cols] (overwritten). */
+/* nn.LayerNorm forward on an FP32 row (the fp32 residual stream of the inference-only encoder): y_bf16 and / or y_f32 receive the
+ * normalised row (bf16 for the next GEMM operand, fp32 for the next residual add).  cols in {256, 512, 768, 1024}. */
+int aptai_layernorm_fwd_f32in(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, int64_t rows,
+                              int64_t cols, float eps, void* stream);
 int aptai_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         const void* dres, void* dx, void* dx_drop, float dropout_p, uint64_t seed, float* dgamma,
                         float* dbeta, void* workspace, int64_t rows, int64_t cols, const float* beta_if_gelu_after,

@@ -372,3 +372,38 @@ def test_force_aptai_prefetched_encoder_is_bit_identical_to_inline():
     model.prefetch(batches[1]["audio_inputs"], batches[1]["audio_lengths"])
     out = model(0, **other)
     assert model._prefetched is None and np.isfinite(out["loss"].item())
+
+
+def test_prefetch_graph_survives_forwards_of_other_batch_shapes():
+    """The captured encoder pass holds the addresses of the recogniser's persistent scratch buffers.  A forward with ANOTHER batch
+    shape in between (validation at batch 1 between training epochs) used to replace those buffers and the next replays read
+    freed memory (NaN after a few steps): scratch buffers are now kept per size.  Replay == eager, bit for bit, before and
+    after interleaved batch-1 and batch-2 forwards."""
+    from oracle import synth
+    from aptai_amd.config import W2V2Config
+    z, meta = load_golden("force_aptai_1x2s")
+    pr_cfg = W2V2Config.from_any(meta["pr_cfg"])
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, meta["vocab_len"]), meta["seed"])
+    model, _ = _build(meta, sd)
+    model.train()
+    bs = [{k: v.cuda() for k, v in synth.synth_aptai_batch(pr_cfg, 2, 16000, seed=s, n_phn=40).items()} for s in (1, 2, 3)]
+    b1 = {k: v.cuda() for k, v in synth.synth_aptai_batch(pr_cfg, 1, 16000, seed=9, n_phn=40).items()}
+
+    def check(i):
+        b = bs[i]
+        model.prefetch(b["audio_inputs"], b["audio_lengths"])
+        enc = model._take_prefetched(b["audio_inputs"], b["audio_lengths"])
+        with torch.no_grad():
+            ref = model._encode(b["audio_inputs"], b["audio_lengths"])
+        torch.cuda.synchronize()
+        assert torch.isfinite(enc.ac).all() and torch.equal(enc.ac, ref.ac) and torch.equal(enc.ids, ref.ids), i
+    for i in (0, 1, 2, 0):                       # eager, capture, replays
+        check(i)
+    assert any(g is not None for g in model._enc_graphs.values())
+    model.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            model._encode(b1["audio_inputs"], b1["audio_lengths"])     # another shape through the same persistent scratch keys
+    model.train()
+    for i in (1, 2, 0, 1):
+        check(i)

@@ -415,3 +415,55 @@ def test_module_forwards_stand_alone_against_the_oracle():
     a_o = att.clone().unsqueeze(1).requires_grad_(True)
     heads_ref.forward_sum_loss(a_o, [int(v) for v in z["b2/text_lens"]], [int(v) for v in z["b2/mel_lens"]]).backward()
     assert rel(a_g.grad, a_o.grad) < 2e-3
+
+
+def test_fp32_residual_stream_ops():
+    """The two kernels behind set_encoder_precision("bf16_f32res"): LayerNorm on an fp32 row with bf16 + fp32 outputs, and the GEMM's
+    fp32 output with an fp32 residual added in the epilogue."""
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(300, 768, generator=g) * 3 + 0.5
+    gam, bet = torch.randn(768, generator=g), torch.randn(768, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (768,), gam, bet, 1e-5)
+    y, y32 = ops.layernorm_fwd_f32in(x.cuda(), gam.cuda(), bet.cuda(), 1e-5)
+    assert (y32.cpu() - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
+    assert torch.equal(y.float().cpu(), y32.cpu().to(torch.bfloat16).float())                 # the bf16 copy is the rounded fp32 one
+    a = (torch.randn(256, 512, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(768, 512, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(768, generator=g)
+    res = torch.randn(256, 768, generator=g) * 10
+    for tile in (64, 128, 192):
+        out = ops.gemm(a.cuda(), w.cuda(), 256, 768, 512, bias=bias.cuda(), out_f32=True, residual_f32=res.cuda(), tile=tile)
+        want = a.float() @ w.float().t() + bias + res
+        assert out.dtype == torch.float32 and (out.cpu() - want).abs().max().item() < 2e-4 * want.abs().max().item(), tile
+
+
+def test_fp32_residual_stream_shrinks_the_alignment_noise_band():
+    """Force_APTAI alignment against the oracle with the frozen encoder's residual stream in fp32 (opt-in, inference only) next
+    to the default bf16 stream: same exactness rule on every clear-margin frame, and the measured score deviation / the share of
+    frames inside the noise band must not be larger than with the bf16 stream."""
+    from oracle import heads_ref, synth
+    model, pr_cfg, sd, z, meta = _force_setup()
+    model.eval()
+    batch = synth.synth_aptai_batch(pr_cfg, 2, 24000, seed=5, n_phn=40)
+    with torch.no_grad():
+        ref = heads_ref.force_aptai_forward(sd, pr_cfg, batch["audio_inputs"], batch["audio_lengths"], [batch[n] for n in TV])
+    stats = {}
+    for mode in ("bf16", "bf16_f32res"):
+        model.set_encoder_precision(mode)
+        with torch.no_grad():
+            res, g, dec = model._run(batch["audio_inputs"].cuda(), batch["audio_lengths"].cuda(), phn_pred_list=ref["pred_ctc_phn_seq"])
+            lists, frame_lens, phn_lens, _ = model._lists(dec)
+        att_gpu = res[5].view(g.B, g.Tp, 60)[:, :g.T].float().cpu().numpy()
+        align_gpu = res[8].view(g.B, g.Tp)[:, :g.T].cpu().numpy()
+        sg, sr = _att_scores(att_gpu, frame_lens, phn_lens), _att_scores(ref["att"].numpy(), frame_lens, phn_lens)
+        ig = np.concatenate([align_gpu[b, :t] for b, t in enumerate(frame_lens)])
+        ir = np.concatenate([ref["align_idx"][b, :t].numpy() for b, t in enumerate(frame_lens)])
+        eps, frac = margin_exact(f"force alignment B=2 vs oracle, encoder {mode}", ig, ir, sr, sg, max_under=0.10)
+        tv = (res[3].cpu() - ref["tvs_pred"]).abs().max().item() / ref["tvs_pred"].abs().max().item()
+        stats[mode] = (float(np.max(eps)), frac, tv, int((ig != ir).sum()))
+    model.set_encoder_precision("bf16")
+    print(f"[margin] bf16 stream: max eps {stats['bf16'][0]:.4f}, under-eps share {stats['bf16'][1]:.4f}, tvs dev {stats['bf16'][2]:.4f}, "
+          f"{stats['bf16'][3]} differ | fp32 residual stream: max eps {stats['bf16_f32res'][0]:.4f}, under-eps share "
+          f"{stats['bf16_f32res'][1]:.4f}, tvs dev {stats['bf16_f32res'][2]:.4f}, {stats['bf16_f32res'][3]} differ")
+    assert stats["bf16_f32res"][0] <= stats["bf16"][0] * 1.05 and stats["bf16_f32res"][1] <= stats["bf16"][1] + 0.01
