@@ -373,6 +373,12 @@ class Force_APTAI(nn.Module):
         return {'loss': loss, 'tv_loss': tv_loss, 'align_loss': align_loss, 'tvs_pred': tvs,
                 'pred_frame_phns': pred_frame_phns, 'pred_ctc_phn_seq': phn_pred_list}
 
+    def load_state_dict(self, *args, **kwargs):
+        # the captured encoder passes of prefetch() hold the addresses of the recogniser's bf16 weight copies, which are rebuilt
+        # when the parameters change: drop the graphs (they are re-captured on the next prefetches)
+        self._enc_graphs, self._enc_seen, self._prefetched = {}, {}, None
+        return super().load_state_dict(*args, **kwargs)
+
     def set_encoder_precision(self, precision: str = "bf16"):
         """"bf16_f32res" (default here): bf16 GEMMs, fp32 residual stream; "bf16": all-bf16 stream; "mxfp8": the frozen recogniser's
         transformer Linear layers run with MX block-scaled FP8 operands (BASELINE configs[4]).  The heads stay fp32.  See
