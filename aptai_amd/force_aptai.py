@@ -260,7 +260,8 @@ class Force_APTAI(nn.Module):
         try:
             step0 = self.w2v2_pr.wav2vec2._step
             torch.cuda.synchronize(audio_inputs.device)
-            with torch.cuda.graph(ge.graph, stream=self._enc_stream):
+            # thread-local capture: under data parallelism the process group's watchdog thread polls its events meanwhile
+            with torch.cuda.graph(ge.graph, stream=self._enc_stream, capture_error_mode="thread_local"):
                 ge.out = self._encode(ge.audio, ge.lengths)
             self.w2v2_pr.wav2vec2._step = step0                        # capturing issued nothing
         except Exception as e:                                         # noqa: BLE001 - keep training, eagerly
