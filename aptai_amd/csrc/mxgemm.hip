@@ -4,7 +4,7 @@
 //
 // Only the block-scaled matrix instruction runs FP8 at twice the bf16 rate on gfx950 (v_mfma_scale_f32_32x32x64_f8f6f4: 65 536
 // MACs in the cycles the bf16 32x32x16 form needs for 32 768; the plain fp8 MFMA issues at the bf16 rate - guide, "Matrix cores").
-// Operand map of the 64-deep step, established with exact-integer probes on the hardware (tools/mx_debug3.py): lane l = (row
+// Operand map of the 64-deep step, established with exact-integer probes on the hardware (tools/mx_operand_map.py): lane l = (row
 // l & 31, half h = l >> 5) holds k in [16 h, 16 h + 16) in its first 16 bytes and k in [32 + 16 h, 48 + 16 h) in its second 16
 // bytes, and the scale byte supplied by lane (row, h) applies to the k block [32 h, 32 h + 32) of that row - i.e. to the first
 // 16 bytes of BOTH halves for h = 0 and to the second 16 bytes of both for h = 1.  Fragments are therefore read as two 16-byte

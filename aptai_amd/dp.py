@@ -45,11 +45,23 @@ def _backend_has_avg(group) -> bool:
 class _BucketWork:
     """Handle of one in-flight bucket average; wait() leaves the AVERAGE in `flat[:n]` (on the side stream for device buffers)."""
 
+    # staging buffers of the rs_ag / a2a forms, one set per flat bucket (keyed by its storage): allocated on first use and reused
+    # every step - a bucket is never in flight twice, and nothing is allocated on the side stream inside the step
+    _STAGE = {}
+
     def __init__(self, flat, n, world, group, algo):
         self.flat, self.n, self.world, self.group, self.algo = flat, n, world, group, algo
         self.scale = 1.0 / world
         self.handles = []
         self.stage = None
+
+    def _staging(self, kind, numel, dtype):
+        key = (kind, self.flat.data_ptr(), self.flat.numel(), str(dtype))
+        t = _BucketWork._STAGE.get(key)
+        if t is None or t.numel() != numel:
+            t = torch.empty(numel, device=self.flat.device, dtype=dtype)
+            _BucketWork._STAGE[key] = t
+        return t
 
     def start(self):
         flat, W, g = self.flat, self.world, self.group
@@ -60,7 +72,7 @@ class _BucketWork:
             else:
                 self.handles.append(dist.all_reduce(flat, group=g, async_op=True))
         elif self.algo == "rs_ag":
-            shard = torch.empty(flat.numel() // W, device=flat.device, dtype=flat.dtype)
+            shard = self._staging("shard", flat.numel() // W, flat.dtype)
             if _backend_has_avg(g):
                 dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.AVG, group=g)
                 self.scale = None
@@ -72,9 +84,13 @@ class _BucketWork:
             self.handles.append(dist.all_gather_into_tensor(flat, shard, group=g, async_op=True))
             self.stage = shard
         else:                           # "a2a"
-            recv = torch.empty_like(flat)
+            recv = self._staging("recv", flat.numel(), flat.dtype)
             dist.all_to_all_single(recv, flat, group=g)
-            shard = recv.view(W, -1).float().sum(0).mul_(1.0 / W).to(flat.dtype)
+            # sum of the W received chunks in fp32 (a bf16 running sum would round W - 1 times), averaged, rounded once
+            acc = self._staging("acc32", flat.numel() // W, torch.float32)
+            torch.sum(recv.view(W, -1), dim=0, dtype=torch.float32, out=acc)
+            shard = self._staging("shard", flat.numel() // W, flat.dtype)
+            shard.copy_(acc.mul_(1.0 / W))
             self.scale = None
             self.handles.append(dist.all_gather_into_tensor(flat, shard, group=g, async_op=True))
             self.stage = (recv, shard)

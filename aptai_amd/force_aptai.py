@@ -350,11 +350,17 @@ class Force_APTAI(nn.Module):
 
     def _lists(self, dec):
         """Host views of the decode: (decoded id lists, frame lengths, decoded lengths, phoneme table) - the step's only
-        device->host transfers."""
+        device->host transfers.  The status words of the cooperative BiLSTM kernels (csrc/lstm.hip: every cross-workgroup wait
+        is bounded and raises a status word on timeout) ride in the same transfer as the lengths: a timed-out wait means
+        incomplete hidden states, so it raises here instead of returning a silently wrong `tvs_pred`."""
         ids, nlen, frame_lens, given = dec
-        fl = [int(v) for v in frame_lens.cpu().tolist()]
+        B = int(frame_lens.numel())
+        status = ops.lstm_status_words(ids.device)
+        parts = [frame_lens.reshape(-1).to(torch.int32), nlen.reshape(-1).to(torch.int32)] + ([status] if status is not None else [])
+        host = torch.cat(parts).cpu().tolist()                        # ONE transfer: frame lengths | decoded lengths | LSTM status
+        fl, n = [int(v) for v in host[:B]], [int(v) for v in host[B:2 * B]]
+        ops.lstm_check(host[2 * B:], ids.device)
         table = ids.cpu().numpy()
-        n = [int(v) for v in nlen.cpu().tolist()]
         if given is None:
             # models/force_aptai.py:111 (checked once the lengths are on the host; the device decode filled 60 slots at most)
             assert all(v < self.max_phn_seq_len for v in n), 'Need longer max phoneme sequence length.'

@@ -661,9 +661,10 @@ _LSTM_WS = {}
 
 
 def _lstm_workspace(B: int, device) -> torch.Tensor:
-    """Exchange area of the cooperating LSTM workgroups (zeroed once here; every launch re-zeroes what it uses) + status word."""
+    """Exchange area of the cooperating LSTM workgroups + status word, one per (device, STREAM): two Force_APTAI models, or one
+    model driven from two streams, never share an exchange area (zeroed once here; every launch re-zeroes what it uses)."""
     n = _lib.lib().aptai_lstm_workspace_bytes(B)
-    key = str(device)
+    key = (str(device), _stream())
     ws = _LSTM_WS.get(key)
     if ws is None or ws.numel() < n:
         ws = torch.zeros(n, device=device, dtype=torch.uint8)
@@ -671,10 +672,30 @@ def _lstm_workspace(B: int, device) -> torch.Tensor:
     return ws
 
 
+def lstm_status_words(device):
+    """int32 device tensor with the status word of every LSTM workspace of this device (None if no LSTM has run): lets a caller
+    fold the check into a device->host read it makes anyway (Force_APTAI._lists)."""
+    words = [ws[:4].view(torch.int32) for (d, _), ws in _LSTM_WS.items() if d == str(device)]
+    if not words:
+        return None
+    return words[0] if len(words) == 1 else torch.cat(words)
+
+
+def lstm_check(status_host, device) -> None:
+    """Raises when a bounded wait of the cooperating LSTM kernels timed out (their output is then incomplete); clears the
+    status words so that the next step is judged on its own."""
+    if status_host is not None and any(int(v) != 0 for v in status_host):
+        for (d, _), ws in _LSTM_WS.items():
+            if d == str(device):
+                ws[:4].zero_()
+        raise _lib.AptaiHipError("aptai_lstm: a cross-workgroup wait of the cooperative BiLSTM kernels timed out "
+                                 "(not all 16 workgroups of a cluster were resident together?): hout / dgates are incomplete")
+
+
 def lstm_status(device) -> int:
     """Non-zero if a bounded wait of the cooperating LSTM kernels ever timed out on this device (synchronises)."""
-    ws = _LSTM_WS.get(str(device))
-    return 0 if ws is None else int(ws[:256].view(torch.int32)[0].item())
+    w = lstm_status_words(torch.device(device) if not isinstance(device, torch.device) else device)
+    return 0 if w is None else int(w.abs().max().item())
 
 
 def lstm_fwd(xproj, whh, lens_i32, B, Tp, T, save=True):

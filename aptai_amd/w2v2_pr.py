@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import hostlogic, ops
+from .modules import _LinearFn
 from .wav2vec2 import Wav2Vec2Model, _round_up, _seed
 
 
@@ -136,6 +137,26 @@ class Wav2Vec2_PR(nn.Module):
         ids, n = ids.cpu().numpy(), n.cpu().numpy()
         return [ids[b, :n[b]].astype(np.int64) for b in range(len(n))]
 
+    def get_embeddings_grad(self, audio_inputs, audio_lengths, vocab, intermediate_hidden, latter_hidden):
+        """models/w2v2_pr.py:91-122: the encoder in whatever mode the module is in, WITH gradients (probing / saliency use):
+        the last, an intermediate and a latter hidden state as (batch, feat, time), and `pr_head` applied to each of the three.
+        `features_hidden` (the reference's separate `feature_extractor` pass, :93) is the conv stack's output (batch, 512, time).
+        Gradients flow from every returned tensor into the encoder's trainable parameters."""
+        out = self.wav2vec2(audio_inputs, attention_mask=audio_lengths[:, None], return_dict=True, output_hidden_states=True)
+        g = out._geom
+        W, bvec = self.pr_head.weight, self.pr_head.bias
+
+        def head(h):                                       # nn.Linear on (B, T, H): differentiable, fp32 matrix instruction
+            return _LinearFn.apply(h, W, bvec)
+        last = out.last_hidden_state
+        inter = out.hidden_states[intermediate_hidden]
+        latter = out.hidden_states[latter_hidden]
+        feats = getattr(out, "_features", None)
+        return {'features_hidden': None if feats is None else feats.view(g.B, g.Tp, -1)[:, :g.T].permute(0, 2, 1),
+                'last_transf_hidden': last.permute(0, 2, 1),
+                'phoneme_logits_last': head(last), 'phoneme_logits_inter': head(inter), 'phoneme_logits_latter': head(latter),
+                'intermediate_hidden': inter.permute(0, 2, 1), 'latter_hidden': latter.permute(0, 2, 1)}
+
     def get_embeddings(self, audio_inputs, audio_lengths):
         """models/w2v2_pr.py:124-167 (the encoder runs ONCE: the reference's extra feature_extractor pass :129 only
         produced 'features_hidden', which no caller reads; it is returned as None)."""
@@ -181,7 +202,7 @@ class Wav2Vec2_PR(nn.Module):
             frame_sec_ratio = len(wav) / logits.size(1) / 16000
             keep = np.ones(len(ids), dtype=bool)
             keep[1:] = ids[1:] != ids[:-1]
-            ts = np.nonzero(keep & (ids != 0))[0]
+            ts = np.nonzero(keep & (ids != self._blank()))[0]
             idx = ids[ts]
             inv = {v: k for k, v in vocab.items()}
             return {'phn_seq_idx': idx, 'phn_seq_ipa': [inv.get(int(i), '?') for i in idx],

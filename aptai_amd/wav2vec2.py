@@ -930,6 +930,7 @@ class Wav2Vec2Model(nn.Module):
         out._geom = g
         out._frame_lens = frame_lens
         out._flat_last = h
+        out._features = feats
         return out
 
 

@@ -70,6 +70,31 @@ def _free_port() -> int:
     return p
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process may use, counted WITHOUT opening the HIP runtime (the parent of the ranks must never hold the devices):
+    KFD topology nodes with SIMDs (/sys/class/kfd/kfd/topology/nodes/*/properties; CPU nodes have simd_count 0), narrowed by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  Returns -1 if the topology is unreadable (the
+    ranks' own `torch.cuda.set_device` then reports a missing device)."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return -1
+    for f in nodes:
+        try:
+            with open(f) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+        except OSError:
+            return -1
+        if int(props.get("simd_count", 0)) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks_if_needed(args) -> None:
     """`python bench.py --gpus N` without a launcher: start N ranks of this file under torch.distributed.run and exit with
     their status.  Runs BEFORE anything touches the GPU in this process (a process that initialised HIP must never be
@@ -83,8 +108,8 @@ def launch_ranks_if_needed(args) -> None:
         return
     backend = os.environ.get("APTAI_BENCH_BACKEND", "nccl")
     if backend == "nccl":
-        n_dev = torch.cuda.device_count()                    # counting devices does not initialise HIP on this image
-        if n_dev < args.gpus:
+        n_dev = visible_gpu_count()                          # sysfs only: nothing in the parent opens the HIP runtime
+        if 0 <= n_dev < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} GPU(s); refusing to measure fewer "
                              f"ranks than asked (APTAI_BENCH_BACKEND=gloo rehearses the multi-rank path on one card)")
     env = dict(os.environ)
@@ -530,6 +555,7 @@ def main():
             "config": {"workload": what,
                        "per_gpu_batch": B, "global_batch": world * B, "clip_seconds": args.seconds,
                        "parallelism": f"dp{world}", "ranks": world,
+                       "process_group_world_size": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1),
                        "collective": (f"{backend} ({'RCCL over xGMI' if backend == 'nccl' else 'rehearsal on CPU tensors'}), "
                                       f"bucket average = {default_algo()}") if world > 1 else None,
                        "regularisers": "off" if args.no_regularisers else "HF defaults",

@@ -145,6 +145,21 @@ def pr_get_embeddings(sd, cfg, audio_inputs, audio_lengths, prefix: str = "") ->
     return {"last_transf_hidden": h.permute(0, 2, 1), "phoneme_logits": logits, "frame_seq_lens": lens}
 
 
+def pr_get_embeddings_grad(sd, cfg, audio_inputs, audio_lengths, intermediate_hidden: int, latter_hidden: int,
+                           training: bool = False, prefix: str = "") -> Dict[str, object]:
+    """models/w2v2_pr.py:91-122: encoder WITH autograd (no eval() / no_grad in the reference), the last / an intermediate /
+    a latter hidden state transposed to (batch, feat, time) and `pr_head` on each; `features_hidden` is the separate
+    `feature_extractor` pass of :93 (batch, 512, time)."""
+    feats = w2v2_ref.feature_encoder(sd, cfg, audio_inputs, prefix + "wav2vec2.")
+    out = w2v2_ref.wav2vec2_forward(sd, cfg, audio_inputs, audio_lengths, prefix + "wav2vec2.", training)
+    W, b = sd[prefix + "pr_head.weight"], sd[prefix + "pr_head.bias"]
+    last, inter, latter = out["last_hidden_state"], out["hidden_states"][intermediate_hidden], out["hidden_states"][latter_hidden]
+    return {"features_hidden": feats, "last_transf_hidden": last.permute(0, 2, 1),
+            "phoneme_logits_last": F.linear(last, W, b), "phoneme_logits_inter": F.linear(inter, W, b),
+            "phoneme_logits_latter": F.linear(latter, W, b), "intermediate_hidden": inter.permute(0, 2, 1),
+            "latter_hidden": latter.permute(0, 2, 1)}
+
+
 def ctc_best_path(logits: np.ndarray, blank: int = 0) -> np.ndarray:
     """Greedy stand-in for the torchaudio beam decoder (parity unpinned):
     argmax per frame -> collapse repeats -> drop blank.  NOTE: like the reference's call

@@ -415,8 +415,34 @@ def case_dataprep(name="dataprep_small"):
     save(name, dict(case=name), arrays)
 
 
+def case_pr_embgrad(name="pr_embgrad_2x1s", layers=3, seconds=1.0, seed=0):
+    """Wav2Vec2_PR.get_embeddings_grad (models/w2v2_pr.py:91-122) of the unmodified reference: the seven returned tensors in
+    eval mode (regularisers off) and the gradient norms of sum(phoneme_logits_inter**2) + sum(phoneme_logits_last**2)."""
+    cfg_kw = dict(BASE, num_hidden_layers=layers, vocab_size=40, ctc_loss_reduction="mean", ctc_zero_infinity=True, blank=0, **NOREG)
+    cfg = hf_config(cfg_kw)
+    S = int(16000 * seconds)
+    batch = synth.synth_pr_batch(cfg, 2, S, seed=77, lo=8, hi=12)
+    vocab = {f"p{i}": i for i in range(40)}
+    with tempfile.TemporaryDirectory() as tmp:
+        model = ref_w2v2_pr.Wav2Vec2_PR(cfg, None, local_model_dir(cfg, tmp), vocab)
+    model.load_state_dict(synth.make_state_dict(synth.pr_param_shapes(cfg), seed))
+    model.eval()
+    out = model.get_embeddings_grad(batch["input_values"], batch["input_lengths"], vocab, 1, 2)
+    (out["phoneme_logits_inter"].pow(2).sum() + out["phoneme_logits_last"].pow(2).sum()).backward()
+    arrays = {"out/" + k: v.detach().numpy() for k, v in out.items() if k.startswith("phoneme_logits")}
+    for k in ("last_transf_hidden", "intermediate_hidden", "latter_hidden"):        # (batch, feat, time): every 4th feature
+        arrays["out/" + k + "_sub"] = out[k].detach().numpy()[:, ::4]
+    arrays["out/features_hidden_sub"] = out["features_hidden"].detach().numpy()[:, ::8]
+    picks = {"pr_head.weight", "wav2vec2.encoder.layers.0.attention.q_proj.weight", "wav2vec2.encoder.layers.2.feed_forward.output_dense.weight"}
+    arrays.update(grads_summary(model.named_parameters(), picks))
+    for k, v in batch.items():
+        arrays["in/" + k] = v.numpy()
+    save(name, dict(case=name, cfg=cfg_kw, seed=seed, S=S, batch_seed=77, intermediate_hidden=1, latter_hidden=2,
+                    model="Wav2Vec2_PR.get_embeddings_grad"), arrays)
+
+
 CASES = {"ops": case_ops, "metrics": case_metrics, "dataprep": case_dataprep, "pr_mini": case_pr_base_mini, "pr_base": case_pr_base, "aptai_large": case_aptai_large,
-         "force": case_force}
+         "force": case_force, "pr_embgrad": case_pr_embgrad}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -24,12 +24,46 @@ def _model():
                                torch.nn.Linear(32, 4))
 
 
-def _worker(rank, world, port, comm_bf16, q, algo="allreduce"):
+def _mock_rccl_semantics(world):
+    """gloo has neither ReduceOp.AVG nor reduce_scatter_tensor.  To reach the branches dp.py takes ONLY under the "nccl" (RCCL)
+    backend without RCCL hardware, report the backend as averaging-capable and emulate exactly those two calls on top of gloo:
+    same call signatures, same results, so a typo or a wrong argument in the RCCL-only code surfaces here and not first on the
+    8-GPU run."""
+    import aptai_amd.dp as dp
+    calls = {"avg_all_reduce": 0, "reduce_scatter": 0}
+    real_all_reduce = dist.all_reduce
+    dp._backend_has_avg = lambda group: True
+
+    def all_reduce(tensor, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        if op == dist.ReduceOp.AVG:
+            calls["avg_all_reduce"] += 1
+            w = real_all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=False)
+            tensor.div_(world)
+
+            class _Done:
+                def wait(self):
+                    return True
+            return _Done() if async_op else w
+        return real_all_reduce(tensor, op=op, group=group, async_op=async_op)
+
+    def reduce_scatter_tensor(output, input, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        assert op == dist.ReduceOp.AVG and not async_op and input.numel() == world * output.numel()
+        calls["reduce_scatter"] += 1
+        tmp = input.clone()
+        real_all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        output.copy_(tmp.view(world, -1)[dist.get_rank(group)] / world)
+    dist.all_reduce = all_reduce
+    dist.reduce_scatter_tensor = reduce_scatter_tensor
+    return calls
+
+
+def _worker(rank, world, port, comm_bf16, q, algo="allreduce", mock_rccl=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["APTAI_DP_ALGO"] = algo
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from aptai_amd.dp import GradBucketReducer, shard_batch
+    calls = _mock_rccl_semantics(world) if mock_rccl else None
     model = _model()
     g = torch.Generator().manual_seed(1)
     batch = {"x": torch.randn(8, 16, generator=g), "y": torch.randn(8, 4, generator=g)}
@@ -50,18 +84,23 @@ def _worker(rank, world, port, comm_bf16, q, algo="allreduce"):
     # by value (the sender may exit first); a parameter no rank touched keeps grad None, like the single-process run
     q.put((rank, {n: (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy() for n, p in model.named_parameters()}))
     assert model[2].weight.grad is None
+    if calls is not None:                                   # the RCCL-only branch of this algorithm really ran
+        assert calls["avg_all_reduce" if algo == "allreduce" else "reduce_scatter"] >= 2, calls
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("comm_bf16,algo", [(False, "allreduce"), (True, "allreduce"), (False, "rs_ag"), (True, "a2a"), (False, "a2a")])
-def test_dp_gradients_equal_single_process(comm_bf16, algo):
+@pytest.mark.parametrize("comm_bf16,algo,mock_rccl", [(False, "allreduce", False), (True, "allreduce", False), (False, "rs_ag", False),
+                                                      (True, "a2a", False), (False, "a2a", False),
+                                                      (False, "allreduce", True), (False, "rs_ag", True)])
+def test_dp_gradients_equal_single_process(comm_bf16, algo, mock_rccl):
     """Every bucket-averaging pattern of aptai_amd.dp (all-reduce, reduce-scatter + all-gather, direct all-to-all) gives the
-    single-process gradient of the whole batch."""
+    single-process gradient of the whole batch.  mock_rccl: the branches only the "nccl" backend takes (ReduceOp.AVG all-reduce,
+    reduce_scatter_tensor with AVG), reached through an emulation of those two calls over gloo."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, comm_bf16, q, algo)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, comm_bf16, q, algo, mock_rccl)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(world))

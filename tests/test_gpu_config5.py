@@ -58,7 +58,7 @@ def test_force_aptai_large_30s_against_the_oracle_at_reduced_depth():
     sg, sr = _att_scores(att_gpu, frame_lens, phn_lens), _att_scores(ref["att"].numpy(), frame_lens, phn_lens)
     ig = np.concatenate([res[8].view(g.B, g.Tp)[b, :t].cpu().numpy() for b, t in enumerate(frame_lens)])
     ir = np.concatenate([ref["align_idx"][b, :t].numpy() for b, t in enumerate(frame_lens)])
-    eps, frac = margin_exact("force alignment, large, 30 s, 2 layers", ig, ir, sr, sg, max_under=0.2)        # 12.5 % measured (13.7 % all-bf16)
+    eps, frac = margin_exact("force alignment, large, 30 s, 2 layers", ig, ir, sr, sg, max_under=0.2, max_dev=1.5)        # 12.5 % under eps, deviation 0.98 measured
     got_ids = np.concatenate([np.asarray(out["pred_frame_phns"][b]) for b in range(2)])
     ref_ids = np.concatenate([np.asarray(ref["pred_frame_phns"][b]) for b in range(2)])
     top2 = np.sort(sr, -1)[:, -2:]
@@ -74,7 +74,7 @@ def test_force_aptai_large_30s_against_the_oracle_at_reduced_depth():
     model.set_encoder_precision("bf16_f32res")
     sg2 = _att_scores(res2[5].view(g.B, g.Tp, 60)[:, :g.T].float().cpu().numpy(), frame_lens, phn_lens)
     ig2 = np.concatenate([res2[8].view(g.B, g.Tp)[b, :t].cpu().numpy() for b, t in enumerate(frame_lens)])
-    eps2, frac2 = margin_exact("force alignment, large, 30 s, 2 layers, all-bf16 residual stream", ig2, ir, sr, sg2, max_under=0.2)
+    eps2, frac2 = margin_exact("force alignment, large, 30 s, 2 layers, all-bf16 residual stream", ig2, ir, sr, sg2, max_under=0.2, max_dev=1.6)
     assert frac <= frac2 + 0.02, (frac, frac2)
 
 
@@ -109,3 +109,33 @@ def test_force_aptai_large_30s_full_depth_properties():
     heads = [(n, p) for n, p in model.named_parameters() if not n.startswith("w2v2_pr.") and p.requires_grad]
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in heads)
     assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("w2v2_pr."))
+
+
+def test_force_aptai_large_30s_full_depth_with_the_mxfp8_encoder():
+    """BASELINE configs[4] as written: 24 layers, 30 s, the frozen encoder's Linear layers on MX block-scaled FP8 operands.  No CPU
+    oracle finishes 24 large layers on 30 s in test time, so the gate is relative to the bf16 run of the SAME model (itself gated
+    against the oracle at reduced depth above): trajectories within the E4M3 error level of the bf16 ones, alignment indices equal
+    on every frame whose bf16 top-2 margin exceeds 2 x the score deviation between the two runs (capped absolutely), finite losses."""
+    from oracle import synth
+    model, pr_cfg, _ = _setup(24)
+    model.eval()
+    batch = synth.synth_aptai_batch(pr_cfg, 2, S30, seed=14, n_phn=40)
+    lists = _lists(2, 6)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    runs = {}
+    for mode in ("bf16_f32res", "mxfp8"):
+        model.set_encoder_precision(mode)
+        with torch.no_grad():
+            res, g, dec = model._run(cb["audio_inputs"], cb["audio_lengths"], phn_pred_list=lists)
+            _, frame_lens, phn_lens, _ = model._lists(dec)
+        att = _att_scores(res[5].view(g.B, g.Tp, 60)[:, :g.T].float().cpu().numpy(), frame_lens, phn_lens)
+        idx = np.concatenate([res[8].view(g.B, g.Tp)[b, :t].cpu().numpy() for b, t in enumerate(frame_lens)])
+        runs[mode] = (att, idx, res[3].float().cpu(), res[0].item())
+    model.set_encoder_precision("bf16_f32res")
+    a16, i16, tv16, l16 = runs["bf16_f32res"]
+    a8, i8, tv8, l8 = runs["mxfp8"]
+    assert np.isfinite(l8) and abs(l8 - l16) <= 0.15 * abs(l16), (l8, l16)
+    e = (tv8 - tv16).abs().max().item() / tv16.abs().max().item()
+    print(f"[mxfp8] 24 layers, 30 s: max |tvs(mxfp8) - tvs(bf16)| / max|tvs| = {e:.4f}")
+    assert 1e-4 < e <= 0.3                                              # a real fp8 run, at the E4M3 error level
+    margin_exact("force alignment, large, 30 s, 24 layers, mxfp8 vs bf16 encoder", i8, i16, a16, a8, max_under=0.6, max_dev=8.0)

@@ -185,18 +185,8 @@ def test_force_aptai_golden_b1():
         assert abs(out[k].item() - float(z["b1/" + k])) <= 2e-2 * abs(float(z["b1/" + k])), (k, out[k].item(), z["b1/" + k])
     ref_tv = z["b1/tvs_pred"]
     assert np.abs(out["tvs_pred"].cpu().numpy() - ref_tv).max() <= 4e-2 * np.abs(ref_tv).max()
-    # frame-level alignment: identical wherever the reference's choice is not a near-tie of bf16-encoder size
-    agree = np.mean(np.array(out["pred_frame_phns"][0]) == z["b1/pred_frame_phns"])
-    assert agree >= 0.97, agree
-    # the decode the model makes on its own equals the stored one (same best-path definition)
-    # (parity-unpinned step; the bf16 encoder may flip one near-tie frame argmax -> allow one edit)
-    out2 = model(0, **batch)
-    a, b = list(out2["pred_ctc_phn_seq"][0]), list(z["b1/pred_ctc_phn_seq"])
-    d = [[max(i, j) if 0 in (i, j) else 0 for j in range(len(b) + 1)] for i in range(len(a) + 1)]
-    for i in range(1, len(a) + 1):
-        for j in range(1, len(b) + 1):
-            d[i][j] = min(d[i - 1][j] + 1, d[i][j - 1] + 1, d[i - 1][j - 1] + (a[i - 1] != b[j - 1]))
-    assert d[-1][-1] <= 1, (a, b)
+    # (frame-level alignment indices and the decode: tests/test_gpu_parity2.py::test_force_alignment_indices_exact_outside_the_measured_noise
+    #  compares them exactly on every clear-margin frame of this fixture, with an absolute cap on the score deviation)
     named = dict(model.named_parameters())
     bad = []
     for key in z.files:
@@ -208,8 +198,8 @@ def test_force_aptai_golden_b1():
             # is a noise band around the reference; the exact pin is test_force_aptai_b2_against_oracle (fp32 encoder output
             # fed to the same head kernels: 2e-3)
             print(f"[bands] force b1 gradient norm {n}: deviation {abs(got - ref) / (ref + 1e-30):.4f}")
-            # Measured: phn_emb_layer 0.082, xatt / frame_lin <= 0.015, everything behind the LSTM <= 0.004.
-            band = 0.2 if n.startswith("phn_emb_layer") else 0.05 if n.startswith(("xatt", "frame_lin")) else 0.015
+            # Measured: phn_emb_layer 0.082, xatt / frame_lin <= 0.015, everything behind the LSTM <= 0.004; bands = 1.5-3 x those.
+            band = 0.125 if n.startswith("phn_emb_layer") else 0.04 if n.startswith(("xatt", "frame_lin")) else 0.012
             if abs(got - ref) > band * ref + 1e-7:
                 bad.append((n, got, ref))
     assert not bad, bad
@@ -242,22 +232,23 @@ def test_force_aptai_b2_against_oracle():
     for k in ("loss", "tv_loss", "align_loss"):
         assert abs(out[k].item() - ref[k].item()) <= 2e-2 * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
     assert (out["tvs_pred"].cpu() - ref["tvs_pred"]).abs().max().item() <= 4e-2 * ref["tvs_pred"].abs().max().item()
-    for b in range(2):
-        agree = np.mean(np.array(out["pred_frame_phns"][b]) == np.array(ref["pred_frame_phns"][b]))
-        assert agree >= 0.95, (b, agree)
     named = dict(model.named_parameters())
 
-    def check(tol):
-        bad = []
+    def check(tol, tag):
+        bad, worst = [], {}
         for k, v in sdo.items():
             if v.grad is None:
                 continue
             rel = ((named[k].grad.cpu().double() - v.grad.double()).norm() / (v.grad.double().norm() + 1e-30)).item()
-            if rel > tol:
+            fam = k.split(".")[0]
+            worst[fam] = max(worst.get(fam, 0.0), rel)
+            if rel > (tol[fam] if isinstance(tol, dict) else tol):
                 bad.append((k, round(rel, 5)))
+        print(f"[bands] force b2 head gradients, {tag}: " + ", ".join(f"{f} {r:.4f}" for f, r in worst.items()))
         assert not bad, bad
-    # bf16 encoder in front: the random-weight energies are O(40), so the peaky softmaxes amplify its 2^-9 noise
-    check(0.1)
+    # bf16 encoder in front: the random-weight energies are O(40), so the peaky softmaxes amplify its 2^-9 noise on the
+    # alignment path (per-family bands = ~1.5 x the rel-L2 deviations measured on MI355X, printed as [bands])
+    check({"xatt": 0.06, "frame_lin": 0.06, "phn_emb_layer": 0.08, "rnn": 0.03}, "bf16 encoder")
     # same heads fed the ORACLE's fp32 encoder output: only fp32 summation order differs -> tight agreement, which
     # pins the head kernels' forward AND backward (CrossAttention, forward-sum/CTC, BiLSTM, MLP, FIR) exactly
     with torch.no_grad():
@@ -273,13 +264,15 @@ def test_force_aptai_b2_against_oracle():
     assert (out["tvs_pred"].cpu() - ref["tvs_pred"]).abs().max().item() <= 2e-4
     for b in range(2):
         assert out["pred_frame_phns"][b] == ref["pred_frame_phns"][b]                  # alignment indices bit-exact
-    check(2e-3)
+    check(2e-3, "oracle fp32 embeddings")
 
 
 def test_force_aptai_config3_size_step():
-    """BASELINE configs[2] at full size (wav2vec2-base + forced-alignment heads, 16 x 10 s): one training step through the frozen
-    encoder (inference), CrossAttention, forward-sum CTC, BiLSTM and the TV regression - shapes, padding conventions, finite
-    gradients on the head parameters only, alignment rows that stay inside each utterance's phoneme list."""
+    """The forced-alignment step at 16 x 10 s on the REFERENCE's recogniser width (hidden 1024 / pre-LN / LayerNorm conv stack, the
+    only shape models/force_aptai.py:43 can build) at 2 layers: one training step through the frozen encoder (inference),
+    CrossAttention, forward-sum CTC, BiLSTM and the TV regression - shapes, padding conventions, finite gradients on the head
+    parameters only, alignment rows that stay inside each utterance's phoneme list.  BASELINE configs[2] as written (a 12-layer
+    wav2vec2-BASE recogniser) is tests/test_gpu_force_base.py."""
     from oracle import synth
     from aptai_amd.config import W2V2Config
     z, meta = load_golden("force_aptai_1x2s")
@@ -407,3 +400,39 @@ def test_prefetch_graph_survives_forwards_of_other_batch_shapes():
     model.train()
     for i in (1, 2, 0, 1):
         check(i)
+
+
+def test_lstm_timeout_status_raises_on_the_product_path():
+    """csrc/lstm.hip bounds every cross-workgroup wait and raises a status word on timeout; Force_APTAI reads it with the lengths
+    (one transfer) and must refuse to return lists for a step whose BiLSTM output is incomplete.  Also: the exchange workspace is
+    keyed by (device, stream), so two streams never share one."""
+    from aptai_amd import ops
+    from aptai_amd._lib import AptaiHipError
+    from oracle import synth
+    from aptai_amd.config import W2V2Config
+    z, meta = load_golden("force_aptai_1x2s")
+    pr_cfg = W2V2Config.from_any(meta["pr_cfg"])
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, meta["vocab_len"]), meta["seed"])
+    model, _ = _build(meta, sd)
+    model.eval()
+    b = {k: v.cuda() for k, v in synth.synth_aptai_batch(pr_cfg, 2, 16000, seed=1, n_phn=40).items()}
+    b["phoneme_labels"] = torch.zeros(2, 4, dtype=torch.int32).cuda()
+    lists = [np.arange(2, 12), np.arange(5, 20)]
+    with torch.no_grad():
+        out = model(0, **b, _phn_pred_list=lists)                      # creates this stream's workspace; status clear
+        assert np.isfinite(out["loss"].item())
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            model(0, **b, _phn_pred_list=lists)
+        side.synchronize()
+        k_cur, k_side = ("cuda:0", cur.cuda_stream), ("cuda:0", side.cuda_stream)
+        assert k_cur in ops._LSTM_WS and k_side in ops._LSTM_WS        # the second stream got its own exchange area
+        assert ops._LSTM_WS[k_cur].data_ptr() != ops._LSTM_WS[k_side].data_ptr()
+        ws = ops._LSTM_WS[k_cur]
+        ws[:4].view(torch.int32).fill_(1)                              # what a timed-out wait leaves behind
+        with pytest.raises(AptaiHipError, match="timed out"):
+            model(0, **b, _phn_pred_list=lists)
+        assert ops.lstm_status("cuda:0") == 0                          # cleared by the raise: the next step is judged on its own
+        model(0, **b, _phn_pred_list=lists)

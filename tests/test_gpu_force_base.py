@@ -1,0 +1,121 @@
+"""GPU: BASELINE configs[2] AS WRITTEN - Force_APTAI on a wav2vec2-BASE recogniser (12 layers, hidden 768, GroupNorm after the first
+conv layer, post-LN encoder, 40 phonemes), batch 16 x 10 s.  The reference hard-codes `nn.Linear(1024, ...)` for the frame
+projection (models/force_aptai.py:43), so it cannot build this model and no reference fixture exists: parity is the oracle (which
+is parameterised on hidden_size) at B = 2 x 1.5 s, and size-independent properties at the full 16 x 10 s."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_force import _build
+from test_gpu_parity2 import _att_scores, margin_exact
+
+pytestmark = pytest.mark.gpu
+TV = ("LA", "LP", "JA", "TTCL", "TTCD", "TMCL", "TMCD", "TBCL", "TBCD")
+
+
+def _base_setup(blank_bias=2.5):
+    from aptai_amd.config import W2V2Config
+    from oracle import synth
+    pr_cfg = W2V2Config(vocab_size=40, ctc_loss_reduction="mean", ctc_zero_infinity=True, blank=0)        # the defaults ARE wav2vec2-base
+    assert (pr_cfg.hidden_size, pr_cfg.num_hidden_layers, pr_cfg.feat_extract_norm, pr_cfg.do_stable_layer_norm) == (768, 12, "group", False)
+    meta = dict(pr_cfg=pr_cfg.to_dict(), vocab_len=40, seed=3)
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, 40), meta["seed"])
+    sd["w2v2_pr.pr_head.bias"][0] += blank_bias
+    model, _ = _build(meta, sd)
+    return model, pr_cfg, sd
+
+
+def test_force_aptai_on_wav2vec2_base_against_the_oracle():
+    """B = 2 x 1.5 s through the 12-layer base recogniser: losses, trajectories, alignment indices (exact outside the measured noise
+    band, absolute cap on the score deviation) and - with the oracle's fp32 embeddings fed to the same head kernels - every head
+    gradient to 2e-3."""
+    from oracle import heads_ref, synth
+    model, pr_cfg, sd = _base_setup()
+    batch = synth.synth_aptai_batch(pr_cfg, 2, 24000, seed=6, n_phn=40)
+    sdo = {k: v.clone() for k, v in sd.items()}
+    for k, v in sdo.items():
+        if v.dtype == torch.float32 and not k.startswith("w2v2_pr.") and k != "pe_phn.pe":
+            v.requires_grad_(True)
+    ref = heads_ref.force_aptai_forward(sdo, pr_cfg, batch["audio_inputs"], batch["audio_lengths"], [batch[n] for n in TV])
+    ref["loss"].backward()
+    assert all(1 <= len(l) < 60 for l in ref["pred_ctc_phn_seq"]), [len(l) for l in ref["pred_ctc_phn_seq"]]
+    model.train()
+    model.hidden_drop = model.rnn_drop = 0.0
+    cb = {k: v.cuda() for k, v in batch.items()}
+    cb["phoneme_labels"] = torch.zeros(2, 4, dtype=torch.int32).cuda()
+    out = model(0, **cb, _phn_pred_list=ref["pred_ctc_phn_seq"])
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert out["tvs_pred"].shape == ref["tvs_pred"].shape
+    for k in ("loss", "tv_loss", "align_loss"):
+        assert abs(out[k].item() - ref[k].item()) <= 2e-2 * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
+    assert (out["tvs_pred"].cpu() - ref["tvs_pred"]).abs().max().item() <= 4e-2 * ref["tvs_pred"].abs().max().item()
+    with torch.no_grad():
+        res, g, dec = model._run(cb["audio_inputs"], cb["audio_lengths"], phn_pred_list=ref["pred_ctc_phn_seq"])
+        _, frame_lens, phn_lens, _ = model._lists(dec)
+    sg = _att_scores(res[5].view(g.B, g.Tp, 60)[:, :g.T].float().cpu().numpy(), frame_lens, phn_lens)
+    sr = _att_scores(ref["att"].numpy(), frame_lens, phn_lens)
+    ig = np.concatenate([res[8].view(g.B, g.Tp)[b, :t].cpu().numpy() for b, t in enumerate(frame_lens)])
+    ir = np.concatenate([ref["align_idx"][b, :t].numpy() for b, t in enumerate(frame_lens)])
+    eps, frac = margin_exact("force alignment, wav2vec2-base 12 layers, B=2 vs oracle", ig, ir, sr, sg, max_under=0.15, max_dev=1.0)
+    got_ids = np.concatenate([np.asarray(out["pred_frame_phns"][b]) for b in range(2)])
+    ref_ids = np.concatenate([np.asarray(ref["pred_frame_phns"][b]) for b in range(2)])
+    top2 = np.sort(sr, -1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > eps
+    assert (got_ids[clear] == ref_ids[clear]).all()
+    # same heads on the ORACLE's fp32 encoder output: exact indices and 2e-3 gradients (pins the head kernels at H = 768)
+    with torch.no_grad():
+        e = heads_ref.pr_get_embeddings(sd, pr_cfg, batch["audio_inputs"], batch["audio_lengths"], prefix="w2v2_pr.")
+    ac = torch.zeros(2, g.Tp, pr_cfg.hidden_size)
+    ac[:, :g.T] = e["last_transf_hidden"].permute(0, 2, 1)
+    model.zero_grad(set_to_none=True)
+    out = model(0, **cb, _phn_pred_list=ref["pred_ctc_phn_seq"], _ac_override=ac.view(2 * g.Tp, -1).cuda().contiguous())
+    out["loss"].backward()
+    for b in range(2):
+        assert out["pred_frame_phns"][b] == ref["pred_frame_phns"][b]
+    named = dict(model.named_parameters())
+    bad = []
+    for k, v in sdo.items():
+        if v.grad is not None:
+            rel = ((named[k].grad.cpu().double() - v.grad.double()).norm() / (v.grad.double().norm() + 1e-30)).item()
+            if rel > 2e-3:
+                bad.append((k, round(rel, 5)))
+    assert not bad, bad
+
+
+def test_force_aptai_config3_full_size_step_on_wav2vec2_base():
+    """configs[2] at full size: 16 x 10 s through the 12-layer base recogniser (inference) + aligner + BiLSTM, one training step:
+    shapes, padding conventions, finite gradients on the head parameters only, aligned ids drawn from each utterance's own list,
+    utterance independence (utterance 0 of the batch == the same utterance alone), the LSTM status word clear."""
+    from oracle import synth
+    from aptai_amd import ops
+    model, pr_cfg, _ = _base_setup()
+    model.train()
+    B, S = 16, 160000
+    batch = {k: v.cuda() for k, v in synth.synth_aptai_batch(pr_cfg, B, S, seed=8, n_phn=40).items()}
+    g = torch.Generator().manual_seed(5)
+    lists = [torch.randint(2, 40, (int(torch.randint(20, 56, (1,), generator=g)),), generator=g).numpy() for _ in range(B)]
+    batch["phoneme_labels"] = torch.zeros(B, 4, dtype=torch.int32).cuda()
+    out = model(0, **batch, _phn_pred_list=lists)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert ops.lstm_status("cuda:0") == 0
+    assert out["tvs_pred"].shape == (B, 499, 9)
+    for k in ("loss", "tv_loss", "align_loss"):
+        assert np.isfinite(out[k].item()), k
+    lens = model.w2v2_pr.wav2vec2._get_feat_extract_output_lengths(batch["audio_lengths"].reshape(-1)).tolist()
+    for b in range(B):
+        frames = out["pred_frame_phns"][b]
+        assert len(frames) == lens[b]
+        assert set(int(v) for v in frames) <= set(int(v) for v in lists[b])
+    heads = [(n, p) for n, p in model.named_parameters() if not n.startswith("w2v2_pr.") and p.requires_grad]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in heads), [n for n, p in heads if p.grad is None]
+    assert all(p.grad is None for n, p in model.named_parameters() if n.startswith("w2v2_pr."))
+    model.eval()
+    with torch.no_grad():
+        full = model(0, **batch, _phn_pred_list=lists)
+        one = model(0, **{k: v[:1] for k, v in batch.items()}, _phn_pred_list=lists[:1])
+    # batch 1 runs its LSTM over ALL frames (models/modules.py:209-212), so the comparison needs a full-length utterance 0
+    assert lens[0] == 499
+    assert full["pred_frame_phns"][0] == one["pred_frame_phns"][0]
+    assert (full["tvs_pred"][0] - one["tvs_pred"][0]).abs().max().item() < 1e-4

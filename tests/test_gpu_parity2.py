@@ -24,17 +24,18 @@ pytestmark = pytest.mark.gpu
 TV = ("LA", "LP", "JA", "TTCL", "TTCD", "TMCL", "TMCD", "TBCL", "TBCD")
 
 
-def margin_exact(name, got_idx, ref_idx, ref_scores, got_scores, max_under=0.08, max_dev=None):
+def margin_exact(name, got_idx, ref_idx, ref_scores, got_scores, max_under=0.08, *, max_dev):
     """Exact equality of argmax indices on every decision (row) whose oracle top-2 margin exceeds eps_row = 2 x the largest
     score deviation IN THAT ROW: two scores can only swap order if they move toward each other by more than their gap, so on
-    those rows any mismatch is an indexing error, not arithmetic noise.  Returns (largest eps_row, fraction of rows under eps)."""
+    those rows any mismatch is an indexing error, not arithmetic noise.  eps_row comes from the GPU's own deviation in that row,
+    so `max_dev` (mandatory, ~1.5 x the deviation measured on MI355X for that case) caps it ABSOLUTELY: a bug that corrupts the
+    scores of a few rows cannot raise those rows' eps and excuse itself.  Returns (eps per row, fraction of rows under eps)."""
     ref_scores, got_scores = np.asarray(ref_scores, np.float64), np.asarray(got_scores, np.float64)
     ref_scores = ref_scores.reshape(-1, ref_scores.shape[-1])
     got_scores = got_scores.reshape(ref_scores.shape)
     dev_row = np.abs(got_scores - ref_scores).max(axis=-1)
     dev = float(dev_row.max())
-    if max_dev is not None:
-        assert dev <= max_dev, f"{name}: scores deviate by {dev:.4f} > {max_dev}"
+    assert dev <= max_dev, f"{name}: scores deviate by {dev:.4f} > {max_dev}"
     top2 = np.sort(ref_scores, axis=-1)[..., -2:]
     margin = top2[..., 1] - top2[..., 0]
     clear = margin > 2.0 * dev_row
@@ -204,7 +205,7 @@ def test_pr_inference_helpers_against_the_oracle():
     lg = model.get_ctc_logits(wav)
     assert lg.shape == rl.shape and lg.dtype == np.float32
     assert np.abs(lg - rl).max() < 4e-2 * np.abs(rl).max()
-    eps, frac = margin_exact("pr frame argmax", lg.argmax(-1), rl.argmax(-1), rl, lg, max_under=0.15)
+    eps, frac = margin_exact("pr frame argmax", lg.argmax(-1), rl.argmax(-1), rl, lg, max_under=0.15, max_dev=0.045)      # measured 0.029
     ref_ids = heads_ref.ctc_best_path(rl)
     top2 = np.sort(rl, -1)[:, -2:]
     all_clear = bool(((top2[:, 1] - top2[:, 0]) > eps).all())                 # eps: per-frame vector
@@ -234,6 +235,52 @@ def test_pr_inference_helpers_against_the_oracle():
     assert emb["phoneme_logits"].shape == (1, 40, T) and emb["frame_seq_lens"].tolist() == [T]
     assert list(emb["phn_pred_seq_idx"][0]) == list(got["phn_seq_idx"])
     assert emb["features_hidden"] is None                              # the reference's extra conv pass has no reader
+
+
+def test_get_embeddings_grad_against_the_reference_fixture():
+    """Wav2Vec2_PR.get_embeddings_grad (models/w2v2_pr.py:91-122): the seven returned tensors against the reference-generated
+    `pr_embgrad_2x1s` fixture (bf16 encoder: 1.5e-2 rel-L2 on hidden states and logits), and the gradients that flow from
+    `phoneme_logits_inter` + `phoneme_logits_last` back into the encoder and the head (norms within the bf16 bands)."""
+    from aptai_amd.config import W2V2Config
+    from oracle import synth
+    z, meta = load_golden("pr_embgrad_2x1s")
+    cfg = W2V2Config.from_any(meta["cfg"])
+    sd = synth.make_state_dict(synth.pr_param_shapes(cfg), meta["seed"])
+    model = _pr_model(cfg, sd)
+    model.eval()
+    x, lens = torch.from_numpy(z["in/input_values"]).cuda(), torch.from_numpy(z["in/input_lengths"]).cuda()
+    out = model.get_embeddings_grad(x, lens, model.vocab, meta["intermediate_hidden"], meta["latter_hidden"])
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+    for k in ("phoneme_logits_last", "phoneme_logits_inter", "phoneme_logits_latter"):
+        assert out[k].shape == z["out/" + k].shape and out[k].dtype == torch.float32
+        assert rel(out[k].detach().cpu().numpy(), z["out/" + k]) < 1.5e-2, k
+    for k in ("last_transf_hidden", "intermediate_hidden", "latter_hidden"):
+        got = out[k].detach().float().cpu().numpy()
+        assert got.shape[:2] == (2, cfg.hidden_size) and rel(got[:, ::4], z["out/" + k + "_sub"]) < 1.5e-2, k
+    fh = out["features_hidden"].detach().float().cpu().numpy()
+    assert fh.shape[1] == 512 and rel(fh[:, ::8], z["out/features_hidden_sub"]) < 1.5e-2
+    (out["phoneme_logits_inter"].pow(2).sum() + out["phoneme_logits_last"].pow(2).sum()).backward()
+    torch.cuda.synchronize()
+    named = dict(model.named_parameters())
+    worst, n = 0.0, 0
+    for key in z.files:
+        if key.startswith("gnorm/") and not key.endswith("k_proj.bias"):          # exactly zero in exact arithmetic: noise on both sides
+            name = key[len("gnorm/"):]
+            if name.startswith("wav2vec2.feature_extractor."):
+                continue                                                           # (conv stack: covered by test_gpu_ctc_pr's slices)
+            g = named[name].grad
+            assert g is not None, name
+            ref = float(z[key])
+            dev = abs(g.double().norm().item() - ref) / (ref + 1e-30)
+            worst, n = max(worst, dev), n + 1
+            assert dev <= (0.06 if ("q_proj" in name or "k_proj" in name) else 0.03), (name, dev)
+    print(f"[bands] get_embeddings_grad gradient norms: worst deviation {worst:.4f} over {n} tensors")
+    assert n > 20
+    # layers above `latter_hidden` = last feed nothing but the last logits; the head weight gets both contributions
+    for key in ("pr_head.weight",):
+        gs = named[key].grad.float().flatten()
+        step = max(1, gs.numel() // 512)
+        assert rel(gs[::step][:512].cpu().numpy(), z["gslice/" + key]) < 3e-2
 
 
 # ------------------------------------------------------------------------------------------------ Force_APTAI
@@ -278,7 +325,7 @@ def test_force_alignment_indices_exact_outside_the_measured_noise():
     sg, sr = _att_scores(att_gpu, frame_lens, phn_lens), _att_scores(att_ref, frame_lens, phn_lens)
     ig = np.concatenate([align_gpu[b, :t] for b, t in enumerate(frame_lens)])
     ir = np.concatenate([ref["align_idx"][b, :t].numpy() for b, t in enumerate(frame_lens)])
-    eps, frac = margin_exact("force alignment B=2 vs oracle", ig, ir, sr, sg, max_under=0.10)
+    eps, frac = margin_exact("force alignment B=2 vs oracle", ig, ir, sr, sg, max_under=0.10, max_dev=0.7)      # measured 0.46
     # phoneme ids behind the slots (the gather kernel): same rule, expressed on the returned lists
     fp = res[4].cpu().numpy()
     top2 = np.sort(sr, -1)[:, -2:]
@@ -337,7 +384,8 @@ def test_force_inference_helpers_against_the_oracle():
     assert np.abs(tv_got - tv_ref).max() < 4e-2 * np.abs(tv_ref).max()
     sg = np.array(al.T, np.float64)
     sr = np.array(ra.T, np.float64)
-    eps, _ = margin_exact("get_faptai_output alignment", np.argmax(sg, -1), ref["align_idx"][0].numpy(), sr, sg, max_under=0.10)
+    eps, _ = margin_exact("get_faptai_output alignment", np.argmax(sg, -1), ref["align_idx"][0].numpy(), sr, sg, max_under=0.10,
+                          max_dev=1.1)      # measured 0.71
     t2 = np.sort(sr, -1)[:, -2:]
     clear = (t2[:, 1] - t2[:, 0]) > eps
     assert (np.asarray(out["pred_frame_phns"])[clear] == np.asarray(ref["pred_frame_phns"][0])[clear]).all()
@@ -459,7 +507,7 @@ def test_fp32_residual_stream_shrinks_the_alignment_noise_band():
         sg, sr = _att_scores(att_gpu, frame_lens, phn_lens), _att_scores(ref["att"].numpy(), frame_lens, phn_lens)
         ig = np.concatenate([align_gpu[b, :t] for b, t in enumerate(frame_lens)])
         ir = np.concatenate([ref["align_idx"][b, :t].numpy() for b, t in enumerate(frame_lens)])
-        eps, frac = margin_exact(f"force alignment B=2 vs oracle, encoder {mode}", ig, ir, sr, sg, max_under=0.10)
+        eps, frac = margin_exact(f"force alignment B=2 vs oracle, encoder {mode}", ig, ir, sr, sg, max_under=0.10, max_dev=0.75)     # measured 0.48 / 0.44
         tv = (res[3].cpu() - ref["tvs_pred"]).abs().max().item() / ref["tvs_pred"].abs().max().item()
         stats[mode] = (float(np.max(eps)), frac, tv, int((ig != ir).sum()))
     model.set_encoder_precision("bf16")

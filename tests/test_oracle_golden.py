@@ -15,11 +15,13 @@ def _t(z, k):
     return torch.from_numpy(np.asarray(z[k]))
 
 
-def _check_grads(z, named, prefix="", rtol=2e-3):
+def _check_grads(z, named, prefix="", rtol=2e-3, skip=()):
     n_checked = 0
     for key in z.files:
         if key.startswith(prefix + "gnorm/"):
             name = key[len(prefix + "gnorm/"):]
+            if name.endswith(skip):
+                continue
             g = named[name].grad
             assert g is not None, name
             ref = float(z[key])
@@ -84,7 +86,9 @@ def _pr_case(name):
     assert np.abs(out["phoneme_logits"].detach().numpy() - z["train/phoneme_logits"]).max() < 2e-3
     assert np.abs(out["log_probs"].detach().numpy() - z["train/log_probs"]).max() < 2e-3
     out["loss"].backward()
-    _check_grads(z, sd)
+    # d/d(k_proj.bias) is exactly zero in exact arithmetic (a constant added to every key cancels in the softmax): both sides
+    # hold rounding noise there, which scales with this test's large scalar
+    _check_grads(z, sd, skip=("k_proj.bias",))
     return z, meta, cfg, sd, batch
 
 
@@ -141,7 +145,9 @@ def test_aptai_large():
     # argmax indices: identical wherever the reference's top-2 margin is not a float tie
     assert (out["phn_fc_pred"].numpy() == z["train/phn_fc_pred"]).mean() > 0.999
     out["loss"].backward()
-    _check_grads(z, sd)
+    # d/d(k_proj.bias) is exactly zero in exact arithmetic (a constant added to every key cancels in the softmax): both sides
+    # hold rounding noise there, which scales with this test's large scalar
+    _check_grads(z, sd, skip=("k_proj.bias",))
     assert not z["frozen_has_grad"].any()
 
 
@@ -186,3 +192,27 @@ def test_force_aptai():
         assert np.abs(rnn_out.numpy() - z["b2/rnn_out"]).max() < 1e-4
         tv = heads_ref.lowpass_filter(rnn_out, sd["tv_lowpass.lowpass.weight"].view(-1))
         assert np.abs(tv.numpy() - z["b2/tvs"]).max() < 1e-5
+
+
+def test_pr_get_embeddings_grad_matches_reference():
+    """oracle heads_ref.pr_get_embeddings_grad against the reference's own Wav2Vec2_PR.get_embeddings_grad (models/w2v2_pr.py:91-122)."""
+    z, meta = load_golden("pr_embgrad_2x1s")
+    cfg = W2V2Config.from_any(meta["cfg"])
+    sd = synth.make_state_dict(synth.pr_param_shapes(cfg), meta["seed"])
+    for v in sd.values():
+        if v.dtype == torch.float32:
+            v.requires_grad_(True)
+    out = heads_ref.pr_get_embeddings_grad(sd, cfg, _t(z, "in/input_values"), _t(z, "in/input_lengths"),
+                                           meta["intermediate_hidden"], meta["latter_hidden"])
+    for k in ("phoneme_logits_last", "phoneme_logits_inter", "phoneme_logits_latter"):
+        ref = z["out/" + k]
+        assert np.abs(out[k].detach().numpy() - ref).max() <= 2e-3 * np.abs(ref).max(), k
+    for k in ("last_transf_hidden", "intermediate_hidden", "latter_hidden"):
+        ref = z["out/" + k + "_sub"]
+        assert np.abs(out[k].detach().numpy()[:, ::4] - ref).max() <= 2e-3 * np.abs(ref).max(), k
+    ref = z["out/features_hidden_sub"]
+    assert np.abs(out["features_hidden"].detach().numpy()[:, ::8] - ref).max() <= 2e-3 * np.abs(ref).max()
+    (out["phoneme_logits_inter"].pow(2).sum() + out["phoneme_logits_last"].pow(2).sum()).backward()
+    # d/d(k_proj.bias) is exactly zero in exact arithmetic (a constant added to every key cancels in the softmax): both sides
+    # hold rounding noise there, which scales with this test's large scalar
+    _check_grads(z, sd, skip=("k_proj.bias",))
