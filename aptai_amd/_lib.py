@@ -53,6 +53,8 @@ ARGTYPES = {
     "aptai_aptai_loss_bwd": [_P, _P, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _F, _F, _P, _P, _P, _P, _I64, _P],
     "aptai_aptai_loss_workspace_bytes": [],
     "aptai_gemm_workspace_bytes": [_I64, _I64, _I],
+    "aptai_gemm_sk_workspace_bytes": [],
+    "aptai_gemm_sk_status": [_P, _P, _P],
     "aptai_cast_multi": [_P, _I64, _I64, _P],
     "aptai_posconv_weight_bwd": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "aptai_spec_augment_mask": [_P, _P, _I64, _I64, _F, _I64, _I64, _U64, _P],

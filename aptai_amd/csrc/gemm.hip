@@ -713,41 +713,12 @@ __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ base, long
     }
 }
 
-template <bool A_KM, bool B_KM, bool OUT_F32>
-__global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;            // waves w and w+4 share a SIMD and sit in different groups
-    const int wave_base_tid = wave * 64;
-
-    const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    int tile_m, tile_n;
-    raster2d(bid, g.tiles_m, g.tiles_n, g.raster_gm, tile_m, tile_n);
-    const int m0 = tile_m * T2_BM, n0 = tile_n * T2_BN;
-    if (gridDim.y > 1) {
-        const int bo = blockIdx.y / g.nb_inner, bi = blockIdx.y % g.nb_inner;
-        g.A += bo * g.sA[0] + bi * g.sA[1];
-        g.B += bo * g.sB[0] + bi * g.sB[1];
-        const long co = bo * g.sC[0] + bi * g.sC[1];
-        g.C = OUT_F32 ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
-        if (g.out_pre) g.out_pre += co;
-        if (g.bias) g.bias += bo * g.sBias[0] + bi * g.sBias[1];
-        if (g.residual) g.residual += bo * g.sR[0] + bi * g.sR[1];
-        if (g.aux) g.aux += bo * g.sAux[0] + bi * g.sAux[1];
-    }
-    const int split = blockIdx.z;
-    const int total_kt = g.K / BK;
-    const int kt_begin = split * g.ktiles_per_split;
-    int kt_end = kt_begin + g.ktiles_per_split;
-    kt_end = kt_end < total_kt ? kt_end : total_kt;
-    const int nk = kt_end - kt_begin;
+// ---- main loop of one 256 x 256 tile over K-tiles [kt_begin, kt_begin + nk): prologue, 4-phase loop, drain.  Leaves every
+// wave behind a workgroup barrier with no LDS-DMA outstanding (the staging LDS is free for the epilogue).
+template <bool A_KM, bool B_KM>
+__device__ __forceinline__ void gemm256_mainloop(const GemmArgs& g, char* smem, const int m0, const int n0, const int kt_begin,
+                                                 const int nk, f32x4 (&acc)[2][2][4][2], const int tid, const int lane, const int wr,
+                                                 const int wc, const int wave_base_tid, unsigned* publish_flag = nullptr) {
     const int total_h = 4 * nk;                         // half-tiles in stream order A0 B0 B1 A1 per K-tile
 
     // issue half-tile h of the stream (uniform control flow)
@@ -761,7 +732,6 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
         else stage_half<B_KM>(g.B, g.ldb, n0 + 128, g.N, k0, buf + 3 * T2_HALF_BYTES, tid, wave_base_tid);
     };
 
-    f32x4 acc[2][2][4][2];                              // [qm][qn][i][j]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -778,6 +748,10 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
     if (total_h >= 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // stream-K: the slab stores of the PREVIOUS segment are older than this prologue's loads, vector-memory operations retire in
+    // order, so every wave that passed the counted wait above has drained its write-through stores, and every wave has passed
+    // it once the barrier releases: the ready flag goes out here, its drain hidden under this prologue's own latency
+    if (publish_flag != nullptr && tid == 0) __hip_atomic_store(publish_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
 
     // K-major fragments come through inline asm (Frag<true>): the compiler would put `s_waitcnt vmcnt(0)` in front of the
@@ -849,8 +823,13 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
     if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two groups
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+}
 
-    // ------------------------------------------------------------------ epilogue: 4 passes of 64 rows x 256 cols
+// ---- epilogue of one 256 x 256 tile: 4 passes of 64 rows x 256 cols through the (free) staging LDS; ends behind a barrier
+template <bool OUT_F32>
+__device__ __forceinline__ void gemm256_epilogue(const GemmArgs& g, char* smem, const int m0, const int n0, const int split,
+                                                 const f32x4 (&acc)[2][2][4][2], const int tid, const int lane, const int wr,
+                                                 const int wc) {
     const int flags = g.flags;
     const int cl = (tid & 31) * 8;
     const int n = n0 + cl;
@@ -891,6 +870,12 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = fmaf(v[r], alpha, bias8[r]);
             if (OUT_F32) {
+                if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder)
+                    const float* R = (const float*)g.residual + (long)m * g.ldr + n;
+                    const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+                }
                 float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
                 *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
                 *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -904,6 +889,197 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
             epilogue_chunk(v, g, flags, (long)m, n, auxq, resq, sd0, sd1);
         }
         __syncthreads();
+    }
+}
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+__global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;            // waves w and w+4 share a SIMD and sit in different groups
+    const int wave_base_tid = wave * 64;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int bid = xcd_remap(blockIdx.x, nwg);
+    int tile_m, tile_n;
+    raster2d(bid, g.tiles_m, g.tiles_n, g.raster_gm, tile_m, tile_n);
+    const int m0 = tile_m * T2_BM, n0 = tile_n * T2_BN;
+    if (gridDim.y > 1) {
+        const int bo = blockIdx.y / g.nb_inner, bi = blockIdx.y % g.nb_inner;
+        g.A += bo * g.sA[0] + bi * g.sA[1];
+        g.B += bo * g.sB[0] + bi * g.sB[1];
+        const long co = bo * g.sC[0] + bi * g.sC[1];
+        g.C = OUT_F32 ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
+        if (g.out_pre) g.out_pre += co;
+        if (g.bias) g.bias += bo * g.sBias[0] + bi * g.sBias[1];
+        if (g.residual) g.residual += bo * g.sR[0] + bi * g.sR[1];
+        if (g.aux) g.aux += bo * g.sAux[0] + bi * g.sAux[1];
+    }
+    const int split = blockIdx.z;
+    const int total_kt = g.K / BK;
+    const int kt_begin = split * g.ktiles_per_split;
+    int kt_end = kt_begin + g.ktiles_per_split;
+    kt_end = kt_end < total_kt ? kt_end : total_kt;
+    f32x4 acc[2][2][4][2];                              // [qm][qn][i][j]
+    gemm256_mainloop<A_KM, B_KM>(g, smem, m0, n0, kt_begin, kt_end - kt_begin, acc, tid, lane, wr, wc, wave_base_tid);
+    gemm256_epilogue<OUT_F32>(g, smem, m0, n0, split, acc, tid, lane, wr, wc);
+}
+
+// =====================================================================================================================
+// Stream-K form of the 256 x 256 kernel: ONE persistent workgroup per CU, every workgroup gets the same number (+-1) of
+// (tile, K-tile) iterations, so [8192] x {2304, 3072} outputs (288 / 384 tiles = 1.125 / 1.5 rounds of 256 CUs) cost
+// 1.125 / 1.5 rounds' worth of main loop instead of 2.  Workgroup c owns the iteration range [c T / G, (c + 1) T / G) of the
+// tile-major sequence (T = tiles x K-tiles, G = grid).  A range cuts at most one tile at its start and one at its end:
+//   * the END cut (the K-head of a tile another workgroup finishes) is computed FIRST and published as an fp32 slab in the
+//     accumulator's own register layout (write-through 16-byte stores, then one flag word: guide Guideline 16, R1);
+//   * whole tiles follow, with the ordinary epilogue;
+//   * the START cut (the K-tail of a tile: this workgroup is its OWNER) comes LAST: by then the lower-numbered workgroups that
+//     hold the rest of that tile have long published, the owner adds their slabs to its accumulators and runs the epilogue.
+// A tile's contributors always have lower numbers than its owner and publish before anything else, so a waiting owner never
+// depends on a workgroup that is queued behind it; every wait is bounded all the same (status word, give-up = garbage tile,
+// never a hang).  Flags are self-cleaning: the owner re-zeroes what it consumed, the workspace is zeroed once at allocation.
+struct SkArgs {
+    float* slabs;             // [G][256 * 256] fp32
+    unsigned* flags;          // [G] ready flags (0 / 1); flags[-1 .. ] : see launch
+    unsigned* status;         // set to 1 when a bounded wait gives up
+    int kt_per_tile;
+    int total_iters;          // tiles x K-tiles, < 2^23
+};
+constexpr unsigned SK_SPIN_LIMIT = 1u << 20;        // ~1 s of polling before a wait gives up
+constexpr long SK_SLAB_FLOATS = (long)T2_BM * T2_BN;
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+__global__ __launch_bounds__(T2_THREADS, 2) void gemm256_sk_kernel(GemmArgs g, SkArgs sk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int wave_base_tid = wave * 64;
+    const int G = gridDim.x;
+    const int c = xcd_remap(blockIdx.x, G);             // consecutive workgroups (shared tiles, shared panels) on one XCD
+    const int KT = sk.kt_per_tile;
+    const int total = sk.total_iters;                   // < 2^23 (launcher), so c * total fits 32 bits
+    const int it0 = (int)((unsigned)c * (unsigned)total / (unsigned)G), it1 = (int)((unsigned)(c + 1) * (unsigned)total / (unsigned)G);
+    f32x4 acc[2][2][4][2];
+
+    auto tile_origin = [&](int tile, int& m0, int& n0) {
+        int tile_m, tile_n;
+        raster2d(tile, g.tiles_m, g.tiles_n, g.raster_gm, tile_m, tile_n);
+        m0 = tile_m * T2_BM;
+        n0 = tile_n * T2_BN;
+    };
+
+    // ---- 1. the END cut: K-tiles [kb, kb + n) of a tile whose tail belongs to a later workgroup -> slab c
+    int end_main = it1;
+    unsigned* pending_flag = nullptr;
+    if (it1 % KT != 0) {
+        const int tile = (it1 - 1) / KT;
+        const int seg0 = it0 > tile * KT ? it0 : tile * KT;
+        int m0, n0;
+        tile_origin(tile, m0, n0);
+        gemm256_mainloop<A_KM, B_KM>(g, smem, m0, n0, seg0 - tile * KT, it1 - seg0, acc, tid, lane, wr, wc, wave_base_tid);
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(sk.slabs + (long)c * SK_SLAB_FLOATS), 0, (int)(SK_SLAB_FLOATS * 4), 0x00020000);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned idx = (unsigned)(((a * 2 + b) * 4 + i) * 2 + j);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[a][b][i][j]), rsrc,
+                                                               (idx * T2_THREADS + (unsigned)tid) * 16u, 0, 16);      // aux 16 = sc1
+                    }
+        end_main = seg0;
+        pending_flag = sk.flags + c;                                     // published behind the NEXT segment's prologue wait
+        if (it0 >= end_main) {                                           // nothing follows: drain and publish here
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // EVERY storing wave drains its write-through stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(pending_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pending_flag = nullptr;
+        }
+    }
+    // ---- 2. whole tiles (the first segment is deferred when it starts inside a tile)
+    const bool first_partial = (it0 % KT != 0) && it0 < end_main;
+    const int first_end = (it0 / KT + 1) * KT;                           // <= end_main whenever first_partial
+    for (int it = first_partial ? first_end : it0; it < end_main; it += KT) {
+        int m0, n0;
+        tile_origin(it / KT, m0, n0);
+        gemm256_mainloop<A_KM, B_KM>(g, smem, m0, n0, 0, KT, acc, tid, lane, wr, wc, wave_base_tid, pending_flag);
+        pending_flag = nullptr;
+        gemm256_epilogue<OUT_F32>(g, smem, m0, n0, 0, acc, tid, lane, wr, wc);
+    }
+    // ---- 3. the START cut: this workgroup owns the tile; add the slabs of the workgroups that hold its K-head
+    if (first_partial) {
+        const int tile = it0 / KT;
+        int m0, n0;
+        tile_origin(tile, m0, n0);
+        gemm256_mainloop<A_KM, B_KM>(g, smem, m0, n0, it0 - tile * KT, first_end - it0, acc, tid, lane, wr, wc, wave_base_tid, pending_flag);
+        int cfirst = c - 1;                                              // contributors cfirst .. c-1 (it1(c-1) = it0 > tile * KT)
+        while (cfirst > 0 && (int)((unsigned)cfirst * (unsigned)total / (unsigned)G) > tile * KT) --cfirst;
+        if (tid == 0) {
+            bool ok = true;
+            for (int cp = cfirst; cp < c && ok; ++cp) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(sk.flags + cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    if (++spins > SK_SPIN_LIMIT) { atomicExch(sk.status, 1u); ok = false; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // ONE invalidate of this CU's L1 after the polls
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        // The slabs come in through LDS-DMA into the (free) staging LDS, 64 KiB quarters two deep: no registers are tied up, so a
+        // whole quarter is in flight per wave instead of the 4-8 loads the 256-register budget left room for (a plain-load
+        // version spent ~15 us here).  A lane reads back exactly the bytes its own DMA instructions wrote (wave-uniform base +
+        // lane * 16), so its counted vmcnt is the only ordering needed - no barrier.
+        {
+            constexpr int QI = 8;                                        // accumulator f32x4 per lane and quarter
+            const int nq = 4 * (c - cfirst);
+            auto issue_quarter = [&](int q) {
+                const float* slab = sk.slabs + (long)(cfirst + (q >> 2)) * SK_SLAB_FLOATS;
+                char* dst = smem + (q & 1) * (QI * T2_THREADS * 16);
+#pragma unroll
+                for (int e = 0; e < QI; ++e) {
+                    const int idx = (q & 3) * QI + e;
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(slab + ((long)idx * T2_THREADS + tid) * 4),
+                                                     LDS_PTR(dst + (e * T2_THREADS + wave_base_tid) * 16), 16, 0, 0);
+                }
+            };
+            issue_quarter(0);
+            if (nq > 1) issue_quarter(1);
+            for (int q = 0; q < nq; ++q) {
+                if (q + 1 < nq) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const char* src = smem + (q & 1) * (QI * T2_THREADS * 16);
+                f32x4 part[QI];
+#pragma unroll
+                for (int e = 0; e < QI; ++e) part[e] = *(const f32x4*)(src + (e * T2_THREADS + tid) * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the reads are done before the buffer is refilled
+                if (q + 2 < nq) issue_quarter(q + 2);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int idx = ((a * 2 + b) * 4 + i) * 2 + j;
+                                if ((idx >> 3) == (q & 3)) acc[a][b][i][j] += part[idx & 7];
+                            }
+            }
+            __syncthreads();                                             // the epilogue reuses this LDS: every wave is done reading
+        }
+        if (tid == 0)
+            for (int cp = cfirst; cp < c; ++cp) __hip_atomic_store(sk.flags + cp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gemm256_epilogue<OUT_F32>(g, smem, m0, n0, 0, acc, tid, lane, wr, wc);
     }
 }
 
@@ -923,6 +1099,33 @@ int launch_gemm256(GemmArgs g, int nbatch, int nsplit, hipStream_t stream) {
     return APTAI_OK;
 }
 
+constexpr int SK_MAX_GRID = 256;                         // one workgroup per CU of an MI355X
+constexpr int64_t SK_HEADER_BYTES = 4096;                // status word @0, flags @256 .. 256 + 4 * SK_MAX_GRID
+static inline int64_t sk_workspace_bytes() { return SK_HEADER_BYTES + (int64_t)SK_MAX_GRID * SK_SLAB_FLOATS * 4; }
+
+template <bool A_KM, bool B_KM, bool OUT_F32>
+int launch_gemm256_sk(GemmArgs g, void* ws, hipStream_t stream) {
+    auto kern = gemm256_sk_kernel<A_KM, B_KM, OUT_F32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T2_SMEM);
+        attr_set = true;
+    }
+    g.tiles_m = (int)ceil_div(g.M, T2_BM);
+    g.tiles_n = (int)ceil_div(g.N, T2_BN);
+    SkArgs sk;
+    sk.status = (unsigned*)ws;
+    sk.flags = (unsigned*)((char*)ws + 256);
+    sk.slabs = (float*)((char*)ws + SK_HEADER_BYTES);
+    sk.kt_per_tile = g.K / BK;
+    const long total = (long)g.tiles_m * g.tiles_n * sk.kt_per_tile;
+    if (total >= (1L << 23)) APTAI_FAIL(APTAI_ERR_INVALID, "aptai_gemm_bf16: stream-K iteration count %ld out of range", total);
+    sk.total_iters = (int)total;
+    const int grid = total < SK_MAX_GRID ? (int)total : SK_MAX_GRID;
+    APTAI_LAUNCH(kern, dim3(grid), dim3(T2_THREADS), T2_SMEM, stream, g, sk);
+    APTAI_CHECK_LAUNCH("gemm256_sk_kernel");
+    return APTAI_OK;
+}
 
 // =====================================================================================================================
 // 128 x 192 x 64 tile, 512 threads = 8 waves (2 M-rows x 4 N-columns, wave tile 64 x 48 = 4 x 3 MFMA tiles), ONE block
@@ -1207,8 +1410,8 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     if (d->flags & APTAI_EPI_RESIDUAL) APTAI_REQUIRE(d->residual != nullptr, "aptai_gemm_bf16: EPI_RESIDUAL without residual");
     if (d->flags & APTAI_EPI_RESIDUAL_F32)
         APTAI_REQUIRE(d->residual != nullptr && d->out_f32 && !(d->flags & APTAI_EPI_RESIDUAL) && d->split_k <= 1 && !d->accumulate &&
-                      (d->tile == 128 || d->tile == 64 || d->tile == 192),
-                      "aptai_gemm_bf16: EPI_RESIDUAL_F32 needs fp32 output, a residual, no split-K / accumulate and tile 64, 128 or 192");
+                      (d->tile == 128 || d->tile == 64 || d->tile == 192 || d->tile == 256 || d->tile == 257),
+                      "aptai_gemm_bf16: EPI_RESIDUAL_F32 needs fp32 output, a residual, no split-K / accumulate and an explicit tile");
     if (d->flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) APTAI_REQUIRE(d->aux != nullptr, "aptai_gemm_bf16: EPI_DGELU / EPI_MUL_AUX without aux");
     if (d->flags & APTAI_EPI_PRE_DGELU) APTAI_REQUIRE(d->out_pre != nullptr && (d->flags & APTAI_EPI_GELU), "aptai_gemm_bf16: EPI_PRE_DGELU needs EPI_GELU and out_pre");
 
@@ -1314,6 +1517,13 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         const long t192 = ceil_div(d->M, T3_BM) * ceil_div(d->N, T3_BN) * nbatch * nsplit;
         if (tile == 128 && !d->a_kmajor && !d->b_kmajor && d->M % T3_BM == 0 && d->N % T3_BN == 0 && t192 > 192 && t192 <= 256)
             tile = 192;
+        // ... and where it is a whole number of rounds with a light epilogue (one block per CU leaves GELU / dropout arithmetic
+        // exposed: 8192 x 2304 x 768 with bias only 38.3 vs 40.7-42.8 us for the 64- / 128-row tiles, but 58.0 vs 52.5 us with
+        // bias + GELU + dropout + second output; tools/gemm_round.py)
+        const bool light_epi = !(d->flags & (APTAI_EPI_GELU | APTAI_EPI_DROPOUT | APTAI_EPI_DGELU)) && d->out_pre == nullptr;
+        const bool t192_rounds = tile == 128 && !d->a_kmajor && !d->b_kmajor && d->M % T3_BM == 0 && d->N % T3_BN == 0 && t192 % 256 == 0 &&
+                                 t192 <= 768 && d->K <= 1024 && light_epi && nbatch == 1 && nsplit == 1;
+        if (t192_rounds) tile = 192;
         // GEMMs that fill the 512 slots of the 128-tile kernel badly run as 64 x 128 tiles on 768 slots (3 blocks per CU): base
         // dgrads [8192] x 768 (384 tiles -> 768: 49.1 vs 54.9 us at K = 3072, 38.0 vs 42.9 us at K = 2304), base QKV (1152 tiles =
         // 2.25 rounds -> 2304 = 3 rounds), large [4096] x 1024 outputs (256 tiles -> 512: 13.7 vs 17.5 us at K = 1024, 42.4 vs
@@ -1326,16 +1536,26 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         }
         const long t64 = ceil_div(d->M, 64) * ceil_div(d->N, BN) * nbatch * nsplit;
         const double e64 = (double)t64 / (double)(ceil_div(t64, 768) * 768);
-        if (m64 && tile == 128 && !d->a_kmajor && d->M % 64 == 0 && (t128 <= 512 || m64 != 2) && e64 >= 1.2 * e128) tile = 64;
+        if (m64 && tile == 128 && !t192_rounds && !d->a_kmajor && d->M % 64 == 0 && (t128 <= 512 || m64 != 2) && e64 >= 1.2 * e128) tile = 64;
     }
+    const bool sk_ok = d->sk_workspace != nullptr && d->sk_workspace_bytes >= sk_workspace_bytes() && nbatch == 1 && nsplit == 1 &&
+                       !d->accumulate && d->M >= T2_BM && d->N >= T2_BN;
+    if (tile == 257) APTAI_REQUIRE(sk_ok, "aptai_gemm_bf16: tile 257 (stream-K) needs sk_workspace (aptai_gemm_sk_workspace_bytes), no batching / "
+                                          "split-K / accumulate and M, N >= 256");
     if (tile == 64 && d->a_kmajor) tile = 128;            // 64-row tiles need a K-contiguous A
     // 2-D rasterisation per kernel, measured in the step (rocprofv3 kernel statistics, one box, raster 0 / 8): it pays where both
     // operands are K-major (weight gradients: 146.6 -> 131.8 us for a layer's grouped launch) and marginally in the 192- / 256-tile
     // kernels (36.1 -> 35.3, 195.9 -> 193.8 us); the 128- and 64-row kernels with a K-contiguous A LOSE 5-7 % with it (FFN1 forward
     // 71.5 -> 76.7 us, FFN2 dgrad 63.6 -> 67.1, QKV forward 45.7 -> 48.8): their co-resident tiles then share B panels but
     // spread over 8 A panels, and A is the operand they re-read most
-    if (g.raster_gm < 0) g.raster_gm = ((d->a_kmajor && d->b_kmajor) || tile == 192 || tile == 256) ? 8 : 0;
+    if (g.raster_gm < 0) g.raster_gm = ((d->a_kmajor && d->b_kmajor) || tile == 192 || tile == 256 || tile == 257) ? 8 : 0;
     int rc;
+    if (tile == 257) {
+        if (!d->a_kmajor && !d->b_kmajor) rc = f32 ? launch_gemm256_sk<false, false, true>(g, d->sk_workspace, stream) : launch_gemm256_sk<false, false, false>(g, d->sk_workspace, stream);
+        else if (!d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm256_sk<false, true, true>(g, d->sk_workspace, stream) : launch_gemm256_sk<false, true, false>(g, d->sk_workspace, stream);
+        else if (d->a_kmajor && d->b_kmajor) rc = f32 ? launch_gemm256_sk<true, true, true>(g, d->sk_workspace, stream) : launch_gemm256_sk<true, true, false>(g, d->sk_workspace, stream);
+        else APTAI_FAIL(APTAI_ERR_INVALID, "aptai_gemm_bf16: A K-major with B K-contiguous is not built");
+    } else
     if (tile == 64) {
         if (!d->b_kmajor) rc = f32 ? launch_gemm_m64<false, true>(g, nbatch, nsplit, stream) : launch_gemm_m64<false, false>(g, nbatch, nsplit, stream);
         else rc = f32 ? launch_gemm_m64<true, true>(g, nbatch, nsplit, stream) : launch_gemm_m64<true, false>(g, nbatch, nsplit, stream);
@@ -1405,6 +1625,20 @@ extern "C" int aptai_gemm_bf16_grouped(const aptai_gemm_desc* descs, int n, void
     else { if (f32) APTAI_GROUPED(true, true, true); else APTAI_GROUPED(true, true, false); }
 #undef APTAI_GROUPED
     APTAI_CHECK_LAUNCH("gemm_grouped_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int64_t aptai_gemm_sk_workspace_bytes(void) { return sk_workspace_bytes(); }
+
+extern "C" int aptai_gemm_sk_status(void* sk_workspace, void* stream, int* status_out) {
+    APTAI_REQUIRE(sk_workspace != nullptr && status_out != nullptr, "aptai_gemm_sk_status: null pointer");
+    unsigned v = 0;
+    if (hipMemcpyAsync(&v, sk_workspace, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+        APTAI_FAIL(APTAI_ERR_LAUNCH, "aptai_gemm_sk_status: reading the status word failed");
+    if (v != 0 && hipMemsetAsync(sk_workspace, 0, 4, (hipStream_t)stream) != hipSuccess)
+        APTAI_FAIL(APTAI_ERR_LAUNCH, "aptai_gemm_sk_status: clearing the status word failed");
+    *status_out = (int)v;
     return APTAI_OK;
 }
 

@@ -27,7 +27,36 @@ class GemmDesc(ctypes.Structure):
                 ("batch_outer", c_int), ("batch_inner", c_int),
                 ("batch_stride_a", c_i64 * 2), ("batch_stride_b", c_i64 * 2), ("batch_stride_c", c_i64 * 2),
                 ("batch_stride_bias", c_i64 * 2), ("batch_stride_res", c_i64 * 2), ("batch_stride_aux", c_i64 * 2),
-                ("tile", c_int), ("colscale_n", c_int), ("colscale", c_float)]
+                ("tile", c_int), ("colscale_n", c_int), ("colscale", c_float),
+                ("sk_workspace", c_void_p), ("sk_workspace_bytes", c_i64)]
+
+
+TILE_STREAMK = 257
+_SK_WS = {}
+
+
+def _sk_workspace(device) -> torch.Tensor:
+    """Stream-K workspace (one 256 x 256 fp32 slab per CU + self-cleaning ready flags + status word) of the CURRENT stream:
+    zeroed once here; launches on one stream are serialised, so they share it; another stream gets its own."""
+    key = (str(device), _stream())
+    ws = _SK_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(int(_lib.lib().aptai_gemm_sk_workspace_bytes()), device=device, dtype=torch.uint8)
+        _SK_WS[key] = ws
+    return ws
+
+
+def gemm_sk_check(device=None) -> None:
+    """Raises if a bounded wait of a stream-K GEMM launch gave up since the last check (its output tile was then incomplete).
+    Synchronises: call where the host waits for the device anyway (loss logging, end of an epoch, after a timed region)."""
+    for (d, st), ws in list(_SK_WS.items()):
+        if device is not None and d != str(device):
+            continue
+        out = ctypes.c_int(0)
+        _lib.check(_lib.lib().aptai_gemm_sk_status(c_void_p(ws.data_ptr()), c_void_p(st), ctypes.byref(out)), "aptai_gemm_sk_status")
+        if out.value != 0:
+            raise _lib.AptaiHipError("aptai_gemm_bf16 (stream-K): a wait for another workgroup's partial tile timed out; "
+                                     "the output of that launch is incomplete")
 
 
 class GemmProbe:
@@ -115,6 +144,9 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
     d.flags = flags
     d.split_k, d.accumulate = split_k, int(accumulate)
     d.tile = tile
+    if tile == TILE_STREAMK:          # opt-in only: measured slower than the tile rule's choice on every hot-path shape
+        ws_sk = _sk_workspace(a.device)
+        d.sk_workspace, d.sk_workspace_bytes = ws_sk.data_ptr(), ws_sk.numel()
     if colscale is not None:       # (n_cols, factor): output columns [0, n_cols) *= factor after alpha / bias
         d.colscale_n, d.colscale = int(colscale[0]), float(colscale[1])
     if ldaux is not None:

@@ -80,10 +80,15 @@ typedef struct {
     int64_t batch_stride_a[2], batch_stride_b[2], batch_stride_c[2], batch_stride_bias[2], batch_stride_res[2],
         batch_stride_aux[2];
     int tile;                       /* 0 = auto, 64 = 64x128 tile (3 blocks/CU, K-contiguous A), 128 = 128x128 tile kernel (2 blocks/CU), 192 = 128x192 tile, 3-stage ring
-                                       (1 block/CU), 256 = 256x256 deep-pipelined kernel */
+                                       (1 block/CU), 256 = 256x256 deep-pipelined kernel, 257 = the same tile as a persistent stream-K
+                                       kernel (one workgroup per CU, equal shares of (tile, K-tile) iterations; needs sk_workspace) */
     int colscale_n; float colscale; /* bf16 output: columns [0, colscale_n) *= colscale after alpha / bias (colscale_n % 8 == 0).  The fused
                                        q|k|v projection (HF:495-498) hands the attention kernels Q already multiplied by
                                        head_dim^-0.5 * log2(e) (HF:522 applies the scaling to the projected query too), rounded once */
+    void* sk_workspace;             /* optional, aptai_gemm_sk_workspace_bytes() bytes, ZEROED ONCE by the caller and then owned by ONE stream:
+                                       fp32 partial-tile slabs + ready flags (self-cleaning) + status word of the stream-K kernel.  With it the
+                                       auto rule may pick the stream-K form; without it tile 257 is refused and auto never picks it */
+    int64_t sk_workspace_bytes;
 } aptai_gemm_desc;
 
 int aptai_gemm_bf16(const aptai_gemm_desc* desc, void* stream);
@@ -94,6 +99,11 @@ int aptai_gemm_bf16(const aptai_gemm_desc* desc, void* stream);
  * the problem M = 8, A = ones[K][8] (K-major), row 0 of the [8][N] fp32 result. */
 int aptai_gemm_bf16_grouped(const aptai_gemm_desc* descs, int n, void* stream);
 int64_t aptai_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
+/* Stream-K workspace (independent of the problem: one 256 x 256 fp32 slab per CU + flags) and its status word: non-zero after a
+ * launch in which a bounded wait for another workgroup's slab gave up (that launch's output is then incomplete; never a hang).
+ * aptai_gemm_sk_status copies the word to the host behind everything queued on `stream` (synchronises) and clears it. */
+int64_t aptai_gemm_sk_workspace_bytes(void);
+int aptai_gemm_sk_status(void* sk_workspace, void* stream, int* status_out);
 
 /* ------------------------------------------------------------------------------------------------ LayerNorm
  * y = (x - mean) * rstd * gamma + beta over the channel axis (cols in {256,512,768,1024}), one wave per row.

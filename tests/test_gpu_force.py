@@ -248,7 +248,7 @@ def test_force_aptai_b2_against_oracle():
         assert not bad, bad
     # bf16 encoder in front: the random-weight energies are O(40), so the peaky softmaxes amplify its 2^-9 noise on the
     # alignment path (per-family bands = ~1.5 x the rel-L2 deviations measured on MI355X, printed as [bands])
-    check({"xatt": 0.06, "frame_lin": 0.06, "phn_emb_layer": 0.08, "rnn": 0.03}, "bf16 encoder")
+    check({"xatt": 0.085, "frame_lin": 0.085, "phn_emb_layer": 0.09, "rnn": 0.015}, "bf16 encoder")      # measured 0.056 / 0.055 / 0.058 / 0.010
     # same heads fed the ORACLE's fp32 encoder output: only fp32 summation order differs -> tight agreement, which
     # pins the head kernels' forward AND backward (CrossAttention, forward-sum/CTC, BiLSTM, MLP, FIR) exactly
     with torch.no_grad():

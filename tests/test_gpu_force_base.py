@@ -13,14 +13,16 @@ pytestmark = pytest.mark.gpu
 TV = ("LA", "LP", "JA", "TTCL", "TTCD", "TMCL", "TMCD", "TBCL", "TBCD")
 
 
-def _base_setup(blank_bias=2.5):
+def _base_setup():
+    """Force_APTAI around a 12-layer wav2vec2-base recogniser with synthetic weights.  (A random-weight post-LN stack maps every
+    frame to nearly the same logits, so its own best-path decode is one phoneme long whatever the blank bias: the tests hand the
+    decoded lists to both sides explicitly, as the reduced-depth large-shape tests do.)"""
     from aptai_amd.config import W2V2Config
     from oracle import synth
     pr_cfg = W2V2Config(vocab_size=40, ctc_loss_reduction="mean", ctc_zero_infinity=True, blank=0)        # the defaults ARE wav2vec2-base
     assert (pr_cfg.hidden_size, pr_cfg.num_hidden_layers, pr_cfg.feat_extract_norm, pr_cfg.do_stable_layer_norm) == (768, 12, "group", False)
     meta = dict(pr_cfg=pr_cfg.to_dict(), vocab_len=40, seed=3)
     sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, 40), meta["seed"])
-    sd["w2v2_pr.pr_head.bias"][0] += blank_bias
     model, _ = _build(meta, sd)
     return model, pr_cfg, sd
 
@@ -32,13 +34,15 @@ def test_force_aptai_on_wav2vec2_base_against_the_oracle():
     from oracle import heads_ref, synth
     model, pr_cfg, sd = _base_setup()
     batch = synth.synth_aptai_batch(pr_cfg, 2, 24000, seed=6, n_phn=40)
+    gl = torch.Generator().manual_seed(2)
+    lists = [torch.randint(2, 40, (int(torch.randint(8, 20, (1,), generator=gl)),), generator=gl).numpy() for _ in range(2)]
     sdo = {k: v.clone() for k, v in sd.items()}
     for k, v in sdo.items():
         if v.dtype == torch.float32 and not k.startswith("w2v2_pr.") and k != "pe_phn.pe":
             v.requires_grad_(True)
-    ref = heads_ref.force_aptai_forward(sdo, pr_cfg, batch["audio_inputs"], batch["audio_lengths"], [batch[n] for n in TV])
+    ref = heads_ref.force_aptai_forward(sdo, pr_cfg, batch["audio_inputs"], batch["audio_lengths"], [batch[n] for n in TV],
+                                        phn_pred_list=lists)
     ref["loss"].backward()
-    assert all(1 <= len(l) < 60 for l in ref["pred_ctc_phn_seq"]), [len(l) for l in ref["pred_ctc_phn_seq"]]
     model.train()
     model.hidden_drop = model.rnn_drop = 0.0
     cb = {k: v.cuda() for k, v in batch.items()}
@@ -49,15 +53,15 @@ def test_force_aptai_on_wav2vec2_base_against_the_oracle():
     assert out["tvs_pred"].shape == ref["tvs_pred"].shape
     for k in ("loss", "tv_loss", "align_loss"):
         assert abs(out[k].item() - ref[k].item()) <= 2e-2 * abs(ref[k].item()), (k, out[k].item(), ref[k].item())
-    assert (out["tvs_pred"].cpu() - ref["tvs_pred"]).abs().max().item() <= 4e-2 * ref["tvs_pred"].abs().max().item()
+    assert (out["tvs_pred"].detach().cpu() - ref["tvs_pred"].detach()).abs().max().item() <= 4e-2 * ref["tvs_pred"].detach().abs().max().item()
     with torch.no_grad():
         res, g, dec = model._run(cb["audio_inputs"], cb["audio_lengths"], phn_pred_list=ref["pred_ctc_phn_seq"])
         _, frame_lens, phn_lens, _ = model._lists(dec)
     sg = _att_scores(res[5].view(g.B, g.Tp, 60)[:, :g.T].float().cpu().numpy(), frame_lens, phn_lens)
-    sr = _att_scores(ref["att"].numpy(), frame_lens, phn_lens)
+    sr = _att_scores(ref["att"].detach().numpy(), frame_lens, phn_lens)
     ig = np.concatenate([res[8].view(g.B, g.Tp)[b, :t].cpu().numpy() for b, t in enumerate(frame_lens)])
     ir = np.concatenate([ref["align_idx"][b, :t].numpy() for b, t in enumerate(frame_lens)])
-    eps, frac = margin_exact("force alignment, wav2vec2-base 12 layers, B=2 vs oracle", ig, ir, sr, sg, max_under=0.15, max_dev=1.0)
+    eps, frac = margin_exact("force alignment, wav2vec2-base 12 layers, B=2 vs oracle", ig, ir, sr, sg, max_under=0.15, max_dev=0.4)      # measured 0.26
     got_ids = np.concatenate([np.asarray(out["pred_frame_phns"][b]) for b in range(2)])
     ref_ids = np.concatenate([np.asarray(ref["pred_frame_phns"][b]) for b in range(2)])
     top2 = np.sort(sr, -1)[:, -2:]

@@ -35,11 +35,14 @@ class _TileOps:
         return getattr(self._ops, k)
 
     def gemm(self, *a, **kw):
-        kw.setdefault("tile", self._tile)
+        tile = self._tile
+        if tile == 257 and (a[2] < 256 or a[3] < 256 or kw.get("batch") is not None or kw.get("split_k", 1) > 1 or kw.get("accumulate")):
+            tile = 0                                   # the stream-K form takes un-batched, un-split problems of >= one 256 x 256 tile
+        kw.setdefault("tile", tile)
         return self._ops.gemm(*a, **kw)
 
 
-@pytest.fixture(scope="module", params=[0, 64, 128, 192, 256], ids=["auto", "t64", "t128", "t192", "t256"])
+@pytest.fixture(scope="module", params=[0, 64, 128, 192, 256, 257], ids=["auto", "t64", "t128", "t192", "t256", "streamk"])
 def ops(request):
     from aptai_amd import ops
     return _TileOps(ops, request.param)
@@ -199,3 +202,41 @@ def test_bad_arguments_fail_loudly(ops):
         ops.gemm(a, a, 128, 128, 100)              # K not a multiple of 64
     with pytest.raises(AptaiHipError):
         ops.gemm(a.cpu(), a.cpu(), 128, 128, 64)   # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (8192, 2304, 768), (8192, 768, 3072), (8192, 768, 768), (4096, 4096, 1024),
+                                   (1000, 777 // 8 * 8, 320), (512, 256, 64), (300, 264, 6400), (2048, 2048, 128)])
+def test_stream_k_256_tiles_against_fp32_and_the_tile_kernels(M, N, K):
+    """tile 257: the persistent stream-K form of the 256 x 256 kernel.  Every (tile, K-tile) iteration is computed exactly once
+    whatever the cut (partial tiles published as fp32 slabs and added by the tile's owner), edges included; launches repeat
+    bit-identically (fixed summation order, self-cleaning flags); the status word stays clear."""
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a, b = _rand((M, K), g), _rand((N, K), g, 0.2)
+    ref = a.float() @ b.float().t()
+    ac, bc = a.cuda(), b.cuda()
+    out = ops.gemm(ac, bc, M, N, K, tile=257)
+    _cmp(out, ref)
+    out32 = ops.gemm(ac, bc, M, N, K, tile=257, out_f32=True)
+    assert (out32.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() * (K ** 0.5)
+    for _ in range(3):                                                   # replays: flags were re-zeroed by the owners
+        assert torch.equal(ops.gemm(ac, bc, M, N, K, tile=257), out)
+    # dgrad layout (B K-major) and the wgrad layout (both K-major, fp32 out)
+    bk = b.t().contiguous()
+    _cmp(ops.gemm(ac, bk.cuda(), M, N, K, b_kmajor=True, tile=257), ref)
+    if M % 8 == 0:
+        ak = a.t().contiguous()
+        o = ops.gemm(ak.cuda(), bk.cuda(), M, N, K, a_kmajor=True, b_kmajor=True, out_f32=True, tile=257)
+        assert (o.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() * (K ** 0.5)
+    # heavy epilogue through the owner / whole-tile paths alike
+    bias = torch.randn(N, generator=g)
+    res = _rand((M, N), g)
+    o = ops.gemm(ac, bc, M, N, K, bias=bias.cuda(), residual=res.cuda(), tile=257)
+    _cmp(o, ref + bias + res.float())
+    pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    o = ops.gemm(ac, bc, M, N, K, bias=bias.cuda(), gelu=True, out_pre=pre, tile=257)
+    _cmp(pre, ref + bias)
+    o128 = ops.gemm(ac, bc, M, N, K, bias=bias.cuda(), gelu=True, tile=128)
+    assert (o.float() - o128.float()).abs().max().item() <= 2e-2 * o128.float().abs().max().item()
+    torch.cuda.synchronize()
+    ops.gemm_sk_check()

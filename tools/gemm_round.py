@@ -31,14 +31,17 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g).to(torch.bfloat16)
     print("layout shape tile: plain us (TF/s) | heavy epilogue us")
-    for (n, k) in ((2048, 768), (2048, 3072), (1024, 768), (3072, 768), (2304, 768), (768, 768), (768, 3072), (256, 768), (512, 3072)):
+    shapes = ((3072, 768), (2304, 768), (768, 768), (768, 3072), (2048, 768), (2048, 3072), (1024, 768))
+    if len(sys.argv) > 1 and sys.argv[1] == "short":
+        shapes = shapes[:4]
+    for (n, k) in shapes:
         for km in (False, True):
             a = rnd(M, k)
             b = rnd(k, n) if km else rnd(n, k)
             bias = torch.randn(n, device="cuda")
             res = rnd(M, n)
             pre = torch.empty(M, n, device="cuda", dtype=torch.bfloat16)
-            for tile in (0, 256, 128, 192, 64):
+            for tile in (0, 257, 256, 128, 192, 64):
                 if tile == 192 and (n % 192 or km):
                     continue
                 try:
