@@ -249,6 +249,49 @@ def gemm_mxfp8(aq, a_s, bq, b_s, M, N, K, *, bias=None, gelu=False, residual=Non
     return out
 
 
+# ----------------------------------------------------------------------------- exact (fp32-class) inference path
+def split_f32(x32: torch.Tensor, pieces: int, *, weight_side: bool = False, gelu: bool = False, rows=None, cols=None, ldx=None) -> torch.Tensor:
+    """fp32 [rows][cols] -> bf16 pieces [rows][cols * pieces] in the K-tile-interleaved layout of aptai_split_f32."""
+    _dev(x32)
+    rows = x32.shape[0] if rows is None else rows
+    cols = x32.shape[1] if cols is None else cols
+    out = torch.empty((rows, cols * pieces), device=x32.device, dtype=torch.bfloat16)
+    _lib.call("aptai_split_f32", x32.data_ptr(), ldx if ldx is not None else x32.stride(0), rows, cols, int(weight_side), pieces, int(gelu),
+              out.data_ptr(), cols * pieces, _stream())
+    return out
+
+
+def bias_act_res_f32(x32, *, bias=None, res=None, gelu=False, lens_i32=None, rows_per_b=0, out=None):
+    """y = [res +] gelu_erf?(x + bias) in fp32; rows t >= lens[b] zeroed when lens_i32 is given (aptai_bias_act_res_f32)."""
+    _dev(x32, bias, res, lens_i32, out)
+    rows, cols = x32.shape
+    y = out if out is not None else torch.empty((rows, cols), device=x32.device, dtype=torch.float32)
+    _lib.call("aptai_bias_act_res_f32", x32.data_ptr(), x32.stride(0), _ptr(bias), _ptr(res), res.stride(0) if res is not None else 0,
+              y.data_ptr(), y.stride(0), rows, cols, int(gelu), _ptr(lens_i32), rows_per_b, _stream())
+    return y
+
+
+def softmax_rows_f32(s32, lens_i32, B, heads, Tp):
+    _dev(s32, lens_i32)
+    _lib.call("aptai_softmax_rows_f32", s32.data_ptr(), lens_i32.data_ptr(), B, heads, Tp, _stream())
+    return s32
+
+
+def conv0_fwd_f32(audio, weight, bias, gamma, beta, mode, out32, T_real, T_alloc, stats, eps=1e-5):
+    _dev(audio, weight, bias, gamma, beta, out32, stats)
+    B, S = audio.shape
+    _lib.call("aptai_conv0_fwd_f32", audio.data_ptr(), B, S, weight.data_ptr(), _ptr(bias), gamma.data_ptr(), beta.data_ptr(), mode, eps,
+              out32.data_ptr(), T_real, T_alloc, _ptr(stats), _stream())
+    return out32
+
+
+def gemm_split(a_s: torch.Tensor, w_s: torch.Tensor, M: int, N: int, K: int, pieces: int, *, lda=None, bias=None, residual_f32=None,
+               out=None, ldc=None) -> torch.Tensor:
+    """fp32 C[M][N] = A . W^T (+ bias) (+ fp32 residual) from split operands (split_f32): one NT launch of K' = pieces * K."""
+    return gemm(a_s, w_s, M, N, K * pieces, lda=(lda * pieces if lda is not None else None), out_f32=True, bias=bias,
+                residual_f32=residual_f32, out=out, ldc=ldc, tile=128)
+
+
 # ----------------------------------------------------------------------------- LayerNorm
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), device=device, dtype=torch.uint8)

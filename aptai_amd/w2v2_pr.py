@@ -116,6 +116,20 @@ class Wav2Vec2_PR(nn.Module):
             bp[:V] = self.pr_head.bias.detach()
             return wp, bp
         # padded bf16 head weight: rebuilt only when the parameters moved (eval mode trusts Tensor._version, see _cached)
+        h32 = getattr(out, "_flat_last_f32", None)
+        if h32 is not None and getattr(self.wav2vec2, "_encoder_precision", "bf16") in ("f32x3", "f32x6"):
+            # exact inference pass: the head is an fp32 product too (fp32 matrix instruction), so the frame argmax of the decode
+            # sees fp32 logits
+            def build32():
+                w32 = torch.zeros((Np, H), device=h.device, dtype=torch.float32)
+                w32[:V] = self.pr_head.weight.detach()
+                b32 = torch.zeros(Np, device=h.device, dtype=torch.float32)
+                b32[:V] = self.pr_head.bias.detach()
+                return w32, b32
+            w32, b32 = self.wav2vec2._cached(("pr_head_eval32",), [self.pr_head.weight, self.pr_head.bias], build32)
+            full = ops.linear_f32(h32, w32, b32)
+            out._logits_full = full
+            return out, full.view(g.B, g.Tp, Np)[:, :g.T, :V]
         wp, bp = self.wav2vec2._cached(("pr_head_eval",), [self.pr_head.weight, self.pr_head.bias], build)
         full = ops.gemm(h, wp, g.M, Np, H, bias=bp, out_f32=True)
         out._logits_full = full                                   # [B*Tp][Np] fp32: what the device decode reads

@@ -559,8 +559,13 @@ class Wav2Vec2Model(nn.Module):
         # "bf16_f32res": bf16 GEMM operands and attention, but the RESIDUAL STREAM of the transformer stack in fp32 (LayerNorm reads
         # fp32, out-proj / FFN2 add the fp32 residual in their epilogues) and an fp32 last hidden state for the heads - inference
         # only; shrinks the bf16 noise band of the integer outputs downstream (forced-alignment indices) at ~+10 % encoder time
-        if precision not in ("bf16", "mxfp8", "bf16_f32res"):
-            raise ValueError("encoder precision must be 'bf16', 'mxfp8' or 'bf16_f32res'")
+        # "f32x3" / "f32x6": every matrix product of the encoder (conv stack, projection, the four Linear layers, attention, positional
+        # conv) at fp32-class accuracy - bf16 split-operand products with fp32 accumulation on the bf16 matrix pipe (3 or 6 bf16 x bf16
+        # products per fp32 product, csrc/exact.hip) and the fp32 matrix instruction for attention / positional conv - with fp32
+        # LayerNorm, softmax and erf GELU in between: INFERENCE ONLY, ~3-6 x the bf16 encoder time.  For outputs that must equal the
+        # reference's INDEX for index (Force_APTAI's alignment argmax, the best-path decode).
+        if precision not in ("bf16", "mxfp8", "bf16_f32res", "f32x3", "f32x6"):
+            raise ValueError("encoder precision must be 'bf16', 'mxfp8', 'bf16_f32res', 'f32x3' or 'f32x6'")
         self._encoder_precision = precision
         return self
 
@@ -831,6 +836,137 @@ class Wav2Vec2Model(nn.Module):
                 return self._conv_forward(audio, g, save=False)[0]
         return _ConvStackFn.apply(audio, self, g, *params)
 
+    # ------------------------------------------------------------------ exact (fp32-class) inference pass
+    def _exact_weights(self, P: int):
+        """Split (weight-side) copies of every GEMM weight and the fp32 weight-normed positional-conv weight, built once per
+        parameter version (eval mode trusts Tensor._version, see _cached)."""
+        cfg = self.config
+        cl = self.feature_extractor.conv_layers
+        fp = self.feature_projection
+        pc = self.encoder.pos_conv_embed.conv
+        params = [l.conv.weight for l in cl[1:]] + [fp.projection.weight, pc.parametrizations.weight.original0,
+                                                     pc.parametrizations.weight.original1]
+        for i in range(len(self.encoder.layers)):
+            params += self._layer_params(i)
+
+        def build():
+            w = SimpleNamespace(conv=[], layers=[])
+            for l in cl[1:]:
+                cw = l.conv.weight.detach()                                  # [N][C][kw] -> [N][kw*C] (K index = kw*C + c)
+                w.conv.append(ops.split_f32(cw.permute(0, 2, 1).reshape(cw.shape[0], -1).contiguous(), P, weight_side=True))
+            w.proj = ops.split_f32(fp.projection.weight.detach().contiguous(), P, weight_side=True)
+            # weight_norm(dim=2): w = g * v / ||v||_(0,1) per tap (HF:340-356), fp32, in the kernels' [group][out][kw*Cg + in] layout
+            g0, v = pc.parametrizations.weight.original0.detach(), pc.parametrizations.weight.original1.detach()
+            G = cfg.num_conv_pos_embedding_groups
+            Hh, Cg, Kw = v.shape
+            wn = v * (g0 / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
+            w.posconv = wn.view(G, Cg, Cg, Kw).permute(0, 1, 3, 2).reshape(G, Cg, Kw * Cg).contiguous()
+            for i in range(len(self.encoder.layers)):
+                p = [t.detach() for t in self._layer_params(i)]
+                w.layers.append(SimpleNamespace(
+                    wqkv=ops.split_f32(torch.cat(p[0:3]).contiguous(), P, weight_side=True), bqkv=torch.cat(p[3:6]).contiguous(),
+                    wo=ops.split_f32(p[6].contiguous(), P, weight_side=True), bo=p[7],
+                    w1=ops.split_f32(p[8].contiguous(), P, weight_side=True), b1=p[9],
+                    w2=ops.split_f32(p[10].contiguous(), P, weight_side=True), b2=p[11]))
+            return w
+        return self._cached(("exact", P), params, build)
+
+    def _exact_attention(self, qkv32, lens_i32, g):
+        """softmax(Q K^T / sqrt(d) + key mask) V per head on the fp32 matrix instruction (HF:438-548): scores [B][heads][Tp][Tp] fp32."""
+        cfg = self.config
+        H, heads, B, Tp = cfg.hidden_size, cfg.num_attention_heads, g.B, g.Tp
+        d = H // heads
+        s32 = torch.empty((B, heads, Tp, Tp), device=qkv32.device, dtype=torch.float32)
+        for h in range(heads):
+            ops.sgemm(qkv32[:, h * d:], 3 * H, 1, qkv32[:, H + h * d:], 1, 3 * H, Tp, Tp, d, out=s32[:, h], ldc=Tp, alpha=d ** -0.5,
+                      batch=B, bsa=Tp * 3 * H, bsb=Tp * 3 * H, bsc=heads * Tp * Tp, split_k=1)
+        ops.softmax_rows_f32(s32, lens_i32, B, heads, Tp)
+        ctx = torch.empty((g.M, H), device=qkv32.device, dtype=torch.float32)
+        for h in range(heads):
+            ops.sgemm(s32[:, h], Tp, 1, qkv32[:, 2 * H + h * d:], 3 * H, 1, Tp, d, Tp, out=ctx[:, h * d:], ldc=H, batch=B,
+                      bsa=heads * Tp * Tp, bsb=Tp * 3 * H, bsc=Tp * H, split_k=1)
+        return ctx
+
+    def _forward_exact(self, audio, g, lens_i32, P, output_hidden_states):
+        """The whole encoder in eval mode at fp32-class accuracy (set_encoder_precision("f32x3" | "f32x6")).  Returns
+        (last hidden state fp32 [M][H], list of hidden states fp32)."""
+        cfg = self.config
+        cl = self.feature_extractor.conv_layers
+        dev = audio.device
+        C, H, I, M = 512, cfg.hidden_size, cfg.intermediate_size, g.M
+        eps = cfg.layer_norm_eps
+        W = self._exact_weights(P)
+        layer_mode = cfg.feat_extract_norm == "layer"
+        # ---- feature encoder (HF:382-419)
+        l0 = cl[0]
+        stats = None
+        if not layer_mode:                                   # GroupNorm statistics (double-precision window moments, csrc/conv.hip)
+            scratch = self._scratch(("conv", 0, g.B * g.alloc[0] + 8), (g.B * g.alloc[0] + 8) * C, dev).view(-1, C)
+            stats = ops.conv0_fwd(audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight,
+                                  l0.layer_norm.bias, 0, scratch, g.Tl[0], g.alloc[0], want_stats=True)
+        buf = torch.zeros((g.B * g.alloc[0] + 8, C), device=dev, dtype=torch.float32)
+        ops.conv0_fwd_f32(audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight, l0.layer_norm.bias,
+                          1 if layer_mode else 0, buf, g.Tl[0], g.alloc[0], stats)
+        pending_gelu = False                                 # base: GELU of layer i is applied when layer i+1 splits its input
+        for i in range(1, len(cl)):
+            k, s = cfg.conv_kernel[i], cfg.conv_stride[i]
+            Mi = g.B * g.alloc[i]
+            xs = ops.split_f32(buf, P, gelu=pending_gelu)
+            out = torch.zeros((Mi + 8, C), device=dev, dtype=torch.float32)
+            ops.gemm_split(xs, W.conv[i - 1], Mi, C, k * C, P, lda=s * C, bias=cl[i].conv.bias if cfg.conv_bias else None, out=out, ldc=C)
+            if layer_mode:
+                _, y32 = ops.layernorm_fwd_f32in(out[:Mi], cl[i].layer_norm.weight, cl[i].layer_norm.bias, 1e-5, want_bf16=False)
+                out[:Mi].copy_(y32)
+            buf, pending_gelu = out, True
+        feats = ops.bias_act_res_f32(buf[:M], gelu=True)                                               # [M][512] fp32
+        # ---- feature projection, padded-frame zeroing, positional conv (HF:422-434, 678-681, 326-379)
+        fp = self.feature_projection
+        _, n0 = ops.layernorm_fwd_f32in(feats, fp.layer_norm.weight, fp.layer_norm.bias, eps, want_bf16=False)
+        h0 = ops.gemm_split(ops.split_f32(n0, P), W.proj, M, H, C, P, bias=fp.projection.bias)
+        ops.bias_act_res_f32(h0, lens_i32=lens_i32, rows_per_b=g.Tp, out=h0)
+        G, Kw = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
+        Cg, pad = H // G, Kw // 2
+        rows_p = g.Tp + 2 * pad
+        xg = torch.zeros((G, g.B, rows_p, Cg), device=dev, dtype=torch.float32)
+        xg[:, :, pad:pad + g.Tp].copy_(h0.view(g.B, g.Tp, G, Cg).permute(2, 0, 1, 3))
+        pc = self.encoder.pos_conv_embed.conv
+        conv = torch.empty((M, H), device=dev, dtype=torch.float32)
+        for grp in range(G):
+            ops.sgemm(xg[grp], Cg, 1, W.posconv[grp], 1, Kw * Cg, g.Tp, Cg, Kw * Cg, out=conv[:, grp * Cg:], ldc=H,
+                      bias=pc.bias[grp * Cg:(grp + 1) * Cg], batch=g.B, bsa=rows_p * Cg, bsb=0, bsc=g.Tp * H)
+        h = ops.bias_act_res_f32(conv, gelu=True, res=h0)
+        if not cfg.do_stable_layer_norm:
+            _, h = ops.layernorm_fwd_f32in(h, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias, eps, want_bf16=False)
+        # ---- transformer layers (HF:575-654)
+        hidden = []
+        for i, layer in enumerate(self.encoder.layers):
+            hidden.append(h)
+            w = W.layers[i]
+            ln1, ln2 = layer.layer_norm, layer.final_layer_norm
+            if cfg.do_stable_layer_norm:
+                _, a_in = ops.layernorm_fwd_f32in(h, ln1.weight, ln1.bias, eps, want_bf16=False)
+            else:
+                a_in = h
+            qkv = ops.gemm_split(ops.split_f32(a_in, P), w.wqkv, M, 3 * H, H, P, bias=w.bqkv)
+            ctx = self._exact_attention(qkv, lens_i32, g)
+            s1 = ops.gemm_split(ops.split_f32(ctx, P), w.wo, M, H, H, P, bias=w.bo, residual_f32=h)
+            if cfg.do_stable_layer_norm:
+                _, f_in = ops.layernorm_fwd_f32in(s1, ln2.weight, ln2.bias, eps, want_bf16=False)
+                res2 = s1
+            else:
+                _, f_in = ops.layernorm_fwd_f32in(s1, ln1.weight, ln1.bias, eps, want_bf16=False)
+                res2 = f_in
+            u = ops.gemm_split(ops.split_f32(f_in, P), w.w1, M, I, H, P, bias=w.b1)
+            s2 = ops.gemm_split(ops.split_f32(u, P, gelu=True), w.w2, M, H, I, P, bias=w.b2, residual_f32=res2)
+            if cfg.do_stable_layer_norm:
+                h = s2
+            else:
+                _, h = ops.layernorm_fwd_f32in(s2, ln2.weight, ln2.bias, eps, want_bf16=False)
+        if cfg.do_stable_layer_norm:
+            _, h = ops.layernorm_fwd_f32in(h, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias, eps, want_bf16=False)
+        hidden.append(h)
+        return h, hidden
+
     # ------------------------------------------------------------------ forward
     def forward(self, input_values, attention_mask=None, mask_time_indices=None, output_attentions=None,
                 output_hidden_states=None, return_dict=None, **kw):
@@ -856,6 +992,17 @@ class Wav2Vec2Model(nn.Module):
         seed = _seed(self.base_seed, self._step)
         training = self.training
 
+        prec = getattr(self, "_encoder_precision", "bf16")
+        if prec in ("f32x3", "f32x6") and not training and not torch.is_grad_enabled():
+            if mask_time_indices is not None:
+                raise NotImplementedError("the exact inference pass takes no SpecAugment mask (eval mode never samples one)")
+            h32, hidden32 = self._forward_exact(audio, g, lens_i32, 3 if prec == "f32x3" else 6, output_hidden_states)
+            hb = h32.to(torch.bfloat16)
+            out = Wav2Vec2BaseModelOutput(last_hidden_state=h32.view(B, g.Tp, -1)[:, :g.T], extract_features=None,
+                                          hidden_states=tuple(t.view(B, g.Tp, -1)[:, :g.T] for t in hidden32) if output_hidden_states else None,
+                                          attentions=None)
+            out._geom, out._frame_lens, out._flat_last, out._flat_last_f32, out._features = g, frame_lens, hb, h32, None
+            return out
         feats = self._feature_encoder(audio, g)                                         # [M][512] bf16
         # ---- feature projection + SpecAugment + padded-frame zeroing (HF:429-434, 1272-1316, 678-681)
         spec = None

@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of aptai_amd.optim.Adam")
     ap.add_argument("--host-batch", action="store_true", help="hand the step a pinned HOST batch every iteration (PCIe-inclusive rate; "
                     "never the headline value: DESIGN.md section 8)")
-    ap.add_argument("--encoder-precision", default="bf16_f32res", choices=["bf16_f32res", "bf16", "mxfp8"],
+    ap.add_argument("--encoder-precision", default="bf16_f32res", choices=["bf16_f32res", "bf16", "mxfp8", "f32x3", "f32x6"],
                     help="force workload: precision of the frozen encoder (mxfp8 = BASELINE configs[4]; bf16_f32res = bf16 GEMMs with an fp32 residual stream)")
     ap.add_argument("--eager", action="store_true", help="drive the step through autograd (the drop-in loop) instead of hipGraphs")
     return ap.parse_args()
@@ -550,7 +550,9 @@ def main():
             "metric": "utterances/sec (10 s @ 16 kHz) train-step", "value": round(world * B * args.steps / dt, 3),
             "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if (wl != "force" or args.encoder_precision != "mxfp8") else "mxfp8 (E4M3 + E8M0 block scales) in the encoder's Linear layers, bf16 elsewhere, fp32 heads",
+            "vs_baseline": None, "dtype": ("bf16" if (wl != "force" or args.encoder_precision in ("bf16", "bf16_f32res")) else
+                      "mxfp8 (E4M3 + E8M0 block scales) in the encoder's Linear layers, bf16 elsewhere, fp32 heads" if args.encoder_precision == "mxfp8" else
+                      f"fp32-class encoder ({args.encoder_precision}: bf16 split-operand products, fp32 accumulation and element-wise math), fp32 heads"),
             "data": data_note,
             "config": {"workload": what,
                        "per_gpu_batch": B, "global_batch": world * B, "clip_seconds": args.seconds,

@@ -105,6 +105,29 @@ int64_t aptai_gemm_workspace_bytes(int64_t M, int64_t N, int split_k);
 int64_t aptai_gemm_sk_workspace_bytes(void);
 int aptai_gemm_sk_status(void* sk_workspace, void* stream, int* status_out);
 
+/* ------------------------------------------------------------------------------------------------ exact (fp32-class) inference path
+ * Wav2Vec2Model.set_encoder_precision("f32x3" | "f32x6"): the frozen recogniser inside Force_APTAI (models/force_aptai.py:60-78,
+ * 124-127, inference only) with every matrix product at fp32-class accuracy, so that the alignment argmax (:148-161) and the
+ * best-path decode see the reference's fp32 scores.  aptai_split_f32 turns an fp32 operand [rows][cols] into bf16 pieces in the
+ * K-tile-interleaved layout [row][cols/64][pieces][64] (pattern 0 = activation side: hi,hi,lo | hi,hi,mid,mid,hi,low; pattern 1 =
+ * weight side: hi,lo,hi | hi,mid,hi,mid,low,hi), which aptai_gemm_bf16 (NT, fp32 output, K' = pieces * K, lda' = pieces * lda)
+ * multiplies as hi.hi + hi.lo + lo.hi (+ mid.mid + hi.low + low.hi): relative error ~2^-17 (3 pieces) / ~2^-24 (6 pieces) with
+ * fp32 accumulation.  act = 1 applies the erf-form GELU (ACT2FN["gelu"], HF:267-272,560) before the split. */
+int aptai_split_f32(const float* x, int64_t ldx, int64_t rows, int64_t cols, int pattern, int pieces, int act, void* out, int64_t ldo,
+                    void* stream);
+/* y = [res +] act(x + bias) in fp32 (act 0 none, 1 erf GELU); with lens (int32 [rows / rows_per_b]) rows t >= lens[b] of each block
+ * of rows_per_b rows are zeroed (padded frames, HF:678-681).  In place (y == x) allowed. */
+int aptai_bias_act_res_f32(const float* x, int64_t ldx, const float* bias, const float* res, int64_t ldr, float* y, int64_t ldy,
+                           int64_t rows, int64_t cols, int act, const int32_t* lens, int64_t rows_per_b, void* stream);
+/* softmax over keys, in place on fp32 scores s[B][heads][Tp][Tp]; keys >= lens[b] get probability 0 (HF:452-461 under the
+ * finfo.min key mask of HF:1018-1036). */
+int aptai_softmax_rows_f32(float* s, const int32_t* lens, int64_t B, int64_t heads, int64_t Tp, void* stream);
+/* Conv1d(1,512,10,5) + GroupNorm / LayerNorm + erf GELU with FP32 output [B][T_alloc][512] (HF:260-323); `stats` = the (mean, rstd)
+ * block [B][2][512] of aptai_conv0_fwd in group mode (mode 0), unused in layer mode (mode 1). */
+int aptai_conv0_fwd_f32(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias, const float* gamma,
+                        const float* beta, int mode, float eps, float* out, int64_t T_real, int64_t T_alloc, const float* stats,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------------------ LayerNorm
  * y = (x - mean) * rstd * gamma + beta over the channel axis (cols in {256,512,768,1024}), one wave per row.
  * Replaces nn.LayerNorm at HF:288-299 (conv layers, "layer" mode; gelu_after=1 fuses the GELU of HF:299),
