@@ -23,7 +23,8 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // ---------------------------------------------------------------------------------- error plumbing
 void aptai_set_error(const char* fmt, ...);
-const uint32_t* aptai_seed_salt(const void* stream);   // device pointer to the dropout salt bound to this stream (or null), see runtime.hip
+const uint32_t* aptai_seed_salt(const void* stream);
+const int32_t* aptai_frame_bounds(const void* stream);  // device pointer to {conv0 GroupNorm frame count, FIR frame bound} bound to this stream (or null), see runtime.hip   // device pointer to the dropout salt bound to this stream (or null), see runtime.hip
 #define APTAI_FAIL(code, ...)            \
     do {                                 \
         aptai_set_error(__VA_ARGS__);    \

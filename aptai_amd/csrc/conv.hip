@@ -154,13 +154,17 @@ __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restr
 // mean / rstd per (b, c) from the window moments, in double.  grid (B), 512 threads
 __global__ void conv0_moments_final_kernel(const float* __restrict__ partials, const float* __restrict__ w,
                                            const float* __restrict__ bias, float* __restrict__ stats, int nch, int T_real,
-                                           float eps) {
+                                           float eps, const int* __restrict__ bounds) {
     __shared__ double mom[AC_TERMS];
     const int b = blockIdx.x, c = threadIdx.x;
     if (c < AC_TERMS) {
         double s = 0.0;
         for (int k = 0; k < nch; ++k) s += (double)partials[((long)b * nch + k) * AC_TERMS + c];
-        mom[c] = s / T_real;
+        // bucketed hipGraphs: the waveform beyond the batch's own padded length is zero, so the sums are those of the batch as
+        // collated; only the frame COUNT of the statistics follows the bound (runtime.hip, aptai_set_frame_bounds)
+        int tdiv = T_real;
+        if (bounds != nullptr) { const int tb = bounds[0]; tdiv = tb < 1 ? 1 : (tb < T_real ? tb : T_real); }
+        mom[c] = s / tdiv;
     }
     __syncthreads();
     double wk[KW];
@@ -328,8 +332,10 @@ __global__ __launch_bounds__(256) void conv0_bwd_group_stats_kernel(Conv0BwdArgs
 // block = 64 channels x 16 chunk slices, the slices meet in LDS in slice order (deterministic).
 __global__ __launch_bounds__(1024) void conv0_bwd_group_final_kernel(const float* __restrict__ gpart, float* __restrict__ gmean,
                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
-                                                                     int nchunks, int T_real) {
+                                                                     int nchunks, int T_real_static, const int* __restrict__ bounds) {
     __shared__ double red[2][16][64];
+    int T_real = T_real_static;
+    if (bounds != nullptr) { const int tb = bounds[0]; T_real = tb < 1 ? 1 : (tb < T_real_static ? tb : T_real_static); }
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double tg = 0.0, tb = 0.0;
@@ -507,7 +513,7 @@ extern "C" int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const f
                  a.partials, nch);
     APTAI_CHECK_LAUNCH("conv0_moments_kernel");
     APTAI_LAUNCH(conv0_moments_final_kernel, dim3((unsigned)B), dim3(C0), 0, stream, (const float*)a.partials, weight, bias,
-                 stats, nch, (int)T_real, eps);
+                 stats, nch, (int)T_real, eps, (const int*)aptai_frame_bounds(stream_));
     APTAI_CHECK_LAUNCH("conv0_moments_final_kernel");
     APTAI_LAUNCH(conv0_group_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, a);
     APTAI_CHECK_LAUNCH("conv0_group_kernel");
@@ -545,7 +551,7 @@ extern "C" int aptai_conv0_bwd(const float* audio, int64_t B, int64_t S, const f
         APTAI_LAUNCH(conv0_bwd_group_stats_kernel, grid, dim3(256), 0, stream, a);
         APTAI_CHECK_LAUNCH("conv0_bwd_group_stats_kernel");
         APTAI_LAUNCH(conv0_bwd_group_final_kernel, dim3(C0 / 64), dim3(1024), 0, stream, (const float*)a.gpart, gmean, dgamma, dbeta, (int)B,
-                     a.f.nchunks, (int)T_real);
+                     a.f.nchunks, (int)T_real, (const int*)aptai_frame_bounds((const void*)stream));
         APTAI_CHECK_LAUNCH("conv0_bwd_group_final_kernel");
         APTAI_LAUNCH(conv0_bwd_weight_kernel<0>, grid, dim3(256), 0, stream, a);
     } else {

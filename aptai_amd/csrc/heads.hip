@@ -11,8 +11,13 @@ constexpr int MAXTAPS = 64;
 // in:  fp32 with row stride ldx (rows b*Tp_in + t);  out: fp32 (ldy) or bf16 (ldy) with zero fill of cols >= C.
 template <bool OUT_BF16>
 __global__ void fir_kernel(const float* __restrict__ x, long ldx, long rows_per_b_in, const double* __restrict__ taps, int ntaps,
-                           void* __restrict__ y, long ldy, long rows_per_b_out, int B, int T, int T_out, int C, int C_out) {
+                           void* __restrict__ y, long ldy, long rows_per_b_out, int B, int T_static, int T_out, int C, int C_out,
+                           const int* __restrict__ bounds) {
     __shared__ double tp[MAXTAPS];
+    // frames at or beyond the bound do not exist for the filter (zero padding starts there) and are written as zeros: a graph
+    // captured for a bucket length then equals the eager run on the batch's own padded length (runtime.hip, aptai_set_frame_bounds)
+    int T = T_static;
+    if (bounds != nullptr) { const int tb = bounds[1]; T = tb < 1 ? 1 : (tb < T_static ? tb : T_static); }
     if ((int)threadIdx.x < ntaps) tp[threadIdx.x] = taps[threadIdx.x];
     __syncthreads();
     const long n = (long)B * T_out * C_out;
@@ -190,10 +195,12 @@ extern "C" int aptai_lowpass_fir(const float* x, int64_t ldx, int64_t rows_per_b
     unsigned blocks = (unsigned)(ceil_div(n, 256) > 2048 ? 2048 : ceil_div(n, 256));
     if (out_bf16)
         APTAI_LAUNCH(fir_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (long)rows_per_b_in,
-                           taps, (int)ntaps, y, (long)ldy, (long)rows_per_b_out, (int)B, (int)T, (int)T_out, (int)C, (int)C_out);
+                           taps, (int)ntaps, y, (long)ldy, (long)rows_per_b_out, (int)B, (int)T, (int)T_out, (int)C, (int)C_out,
+                           (const int*)aptai_frame_bounds(stream));
     else
         APTAI_LAUNCH(fir_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, (long)rows_per_b_in,
-                           taps, (int)ntaps, y, (long)ldy, (long)rows_per_b_out, (int)B, (int)T, (int)T_out, (int)C, (int)C_out);
+                           taps, (int)ntaps, y, (long)ldy, (long)rows_per_b_out, (int)B, (int)T, (int)T_out, (int)C, (int)C_out,
+                           (const int*)aptai_frame_bounds(stream));
     APTAI_CHECK_LAUNCH("fir_kernel");
     return APTAI_OK;
 }

@@ -65,3 +65,36 @@ const uint32_t* aptai_seed_salt(const void* stream) {
     return nullptr;
 }
 
+
+// Optional per-step FRAME BOUNDS, bound to a stream like the salt: a device pointer to two int32 words
+//   [0] frames of the first conv layer that count for its GroupNorm statistics (HF:317-323 normalises over the frames of the batch AS
+//       COLLATED: the reference pads every batch to its own longest utterance, train/train_aptai.py:268-285),
+//   [1] frames of the regression head's output that exist for LowPassFilterLayer's 'same' zero padding (models/modules.py:46-61).
+// A hipGraph captured for a BUCKET length (longer than the batch) replays with the bounds of the batch it is fed, so its results
+// equal the eager run on the batch's own padded length.  Unbound streams use the static sizes they are called with.
+namespace {
+SaltSlot g_bounds[SALT_SLOTS];
+}  // namespace
+
+extern "C" int aptai_set_frame_bounds(void* stream, const void* device_ptr_2xi32) {
+    std::lock_guard<std::mutex> lk(g_salt_mu);
+    int free_slot = -1;
+    for (int i = 0; i < SALT_SLOTS; ++i) {
+        if (g_bounds[i].used && g_bounds[i].stream == stream) {
+            if (device_ptr_2xi32) g_bounds[i].ptr = (const uint32_t*)device_ptr_2xi32;
+            else g_bounds[i].used = false;
+            return APTAI_OK;
+        }
+        if (!g_bounds[i].used && free_slot < 0) free_slot = i;
+    }
+    if (!device_ptr_2xi32) return APTAI_OK;
+    if (free_slot < 0) APTAI_FAIL(APTAI_ERR_INVALID, "aptai_set_frame_bounds: more than %d streams carry bounds", SALT_SLOTS);
+    g_bounds[free_slot] = {stream, (const uint32_t*)device_ptr_2xi32, true};
+    return APTAI_OK;
+}
+const int32_t* aptai_frame_bounds(const void* stream) {
+    std::lock_guard<std::mutex> lk(g_salt_mu);
+    for (int i = 0; i < SALT_SLOTS; ++i)
+        if (g_bounds[i].used && g_bounds[i].stream == stream) return (const int32_t*)g_bounds[i].ptr;
+    return nullptr;
+}

@@ -48,7 +48,18 @@ def _bind_salt(stream_handle: int, salt: torch.Tensor) -> None:
 
 def _unbind_salt(stream_handle: int) -> None:
     _lib.call("aptai_set_seed_salt", stream_handle, None)
+    _lib.call("aptai_set_frame_bounds", stream_handle, None)
     _SALTS.pop(stream_handle, None)
+    _BOUNDS.pop(stream_handle, None)
+
+
+# stream handle -> the device tensor with that stream's frame bounds {conv0 GroupNorm frame count, FIR frame bound}
+_BOUNDS: Dict[int, torch.Tensor] = {}
+
+
+def _bind_bounds(stream_handle: int, bounds: torch.Tensor) -> None:
+    _BOUNDS[stream_handle] = bounds
+    _lib.call("aptai_set_frame_bounds", stream_handle, bounds.data_ptr())
 
 
 class GraphedAPTAIStep:
@@ -94,9 +105,18 @@ class GraphedAPTAIStep:
         # registry keeps the two words alive until the binding is cleared, whatever happens to the runner object
         self._cap_stream = torch.cuda.Stream(device=dev)
         _bind_salt(self._cap_stream.cuda_stream, self.salt)
+        # frame bounds of the batch inside the captured shape (BucketedGraphedStep feeds shorter batches): by default the shape itself
+        self.bounds = torch.tensor([g.Tl[0], g.T], device=dev, dtype=torch.int32)
+        self._bounds_ring = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(4)]
+        self._bounds_events = [None] * 4
+        self._bounds_turn = 0
+        self._bounds_host = (g.Tl[0], g.T)
+        _bind_bounds(self._cap_stream.cuda_stream, self.bounds)
         self.set_batch(batch)
         # one eager step first: allocates every persistent scratch buffer, loads the code objects and sets the kernel
         # attributes outside of stream capture
+        if getattr(w, "_cache_mode", None) == "frozen":          # another runner of this model froze the cache: the eager step rebuilds
+            w._cache_mode = None
         model.zero_grad(set_to_none=True)
         (model(**batch) if self.kind == "pr" else model(0, **batch))["loss"].backward()
         model.zero_grad(set_to_none=True)
@@ -133,6 +153,23 @@ class GraphedAPTAIStep:
         self.lens_i32.copy_(fl.to(torch.int32))
         self.tv_tgt.copy_(torch.stack(tracks, dim=-1).float())
         self.phn_tgt.copy_(batch["phn_frames_49hz"])
+
+    def set_bounds(self, conv0_frames: int, frames: int) -> None:
+        """Frame bounds of the NEXT step's batch inside the captured shape (see aptai_set_frame_bounds): how many first-conv-layer
+        frames count for the GroupNorm statistics and where the low-pass filter's zero padding begins.  No synchronisation (the
+        two words travel through a ring of pinned buffers)."""
+        if (conv0_frames, frames) == self._bounds_host:
+            return
+        slot = self._bounds_turn
+        self._bounds_turn = (slot + 1) % len(self._bounds_ring)
+        if self._bounds_events[slot] is not None:
+            self._bounds_events[slot].synchronize()
+        self._bounds_ring[slot][0], self._bounds_ring[slot][1] = int(conv0_frames), int(frames)
+        self.bounds.copy_(self._bounds_ring[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._bounds_events[slot] = ev
+        self._bounds_host = (conv0_frames, frames)
 
     def _set_batch_pr(self, batch: Dict[str, torch.Tensor]) -> None:
         """Wav2Vec2_PR batch (input_values, input_lengths, phoneme_labels with -100 padding, models/w2v2_pr.py:40-70).  The label
@@ -314,6 +351,9 @@ class GraphedAPTAIStep:
                 self.grads[p] = gt
         for p, gt in zip(w._conv_params(), conv_grads):
             self.grads[p] = gt
+        # the graphs hold raw addresses of the compute copies in the model's cache: keep them alive for this runner's lifetime (a
+        # second runner of the same model - another shape bucket - clears and rebuilds the cache for its own capture)
+        self._keep_cache = dict(w._cache)
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ one optimiser step
@@ -408,6 +448,98 @@ class GraphedAPTAIStep:
                 self._cap_stream = None
         except Exception:               # noqa: BLE001 - interpreter shutdown
             pass
+
+
+class BucketedGraphedStep:
+    """hipGraph replay for REAL batches.  The reference's collate pads every batch to ITS OWN longest utterance
+    (train/train_aptai.py:268-285, train/train_phoneme_recognizer.py:224-239), so the tensor shapes change from step to step,
+    while a captured graph has one shape.  This wrapper keeps a small cache of GraphedAPTAIStep runners, one per (batch size, BUCKET
+    length): a batch is zero-padded up to the next bucket, fed to that bucket's graphs (captured on first use, sharing the model's
+    parameters, persistent weight copies and the optimiser), and the outputs are cut back to the batch's own frame count.
+
+    Results equal the eager loop on the un-bucketed batch: every length-dependent quantity is dynamic inside the graphs -
+    per-utterance frame counts travel as device tensors (attention key mask, padded-frame zeroing, SpecAugment span counts, loss
+    masks, CTC lengths), and the two places where the reference sees the batch's PADDED length (GroupNorm statistics of the first
+    conv layer over all frames of the collated batch; the 'same' zero padding of LowPassFilterLayer) read per-step frame bounds
+    (aptai_set_frame_bounds).  Extra frames of the bucket are padded frames like the reference's own: zeroed, masked as keys, outside
+    every loss, zero gradient.  288 GB of HBM hold a dozen buckets of saved activations (~3.5 GB each at 16 x 10 s)."""
+
+    DEFAULT_SECONDS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 20, 25, 30)
+
+    def __init__(self, model, optimizer, bucket_samples=None, reducer=None, label_bucket: int = 32):
+        self.model, self.opt, self.reducer = model, optimizer, reducer
+        self.kind = "pr" if isinstance(model, Wav2Vec2_PR) else "aptai"
+        self.buckets = sorted(bucket_samples) if bucket_samples else [16000 * s for s in self.DEFAULT_SECONDS]
+        self.label_bucket = label_bucket
+        self.runners: Dict[tuple, GraphedAPTAIStep] = {}
+        self.w = model.wav2vec2
+
+    def bucket_of(self, S: int) -> int:
+        for b in self.buckets:
+            if b >= S:
+                return b
+        return -(-S // 16000) * 16000                      # longer than every bucket: whole seconds
+
+    def _padded(self, batch, Sb: int, Tb: int):
+        akey = "input_values" if self.kind == "pr" else "audio_inputs"
+        out = {}
+        for k, v in batch.items():
+            if k == akey:
+                if v.shape[1] < Sb:
+                    v = torch.nn.functional.pad(v, (0, Sb - v.shape[1]))
+            elif k == "phoneme_labels" and self.kind == "pr":
+                wl = -(-v.shape[1] // self.label_bucket) * self.label_bucket
+                if v.shape[1] < wl:
+                    v = torch.nn.functional.pad(v, (0, wl - v.shape[1]), value=-100)
+            elif k in ("audio_lengths", "input_lengths", "phoneme_labels"):
+                pass
+            elif v.dim() == 2 and self.kind == "aptai":            # frame-rate targets (B, T): -100.0 / 0 = the collate's own padding values
+                if v.shape[1] < Tb:
+                    v = torch.nn.functional.pad(v, (0, Tb - v.shape[1]), value=0 if k == "phn_frames_49hz" else -100.0)
+                elif v.shape[1] > Tb:
+                    v = v[:, :Tb]
+            out[k] = v
+        return out
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        akey = "input_values" if self.kind == "pr" else "audio_inputs"
+        B, S = batch[akey].shape
+        Sb = self.bucket_of(S)
+        g_s, g_b = self.w._geometry(B, S), self.w._geometry(B, Sb)
+        padded = self._padded(batch, Sb, g_b.T)
+        key = (B, Sb) + ((padded["phoneme_labels"].shape[1],) if self.kind == "pr" else ())
+        r = self.runners.get(key)
+        if r is None:
+            dev = next(self.model.parameters()).device
+            r = GraphedAPTAIStep(self.model, self.opt, {k: v.to(dev) for k, v in padded.items()}, reducer=self.reducer)
+            self.runners[key] = r
+        r.set_bounds(g_s.Tl[0], g_s.T)
+        out = r.step(padded)
+        T = g_s.T
+        if self.kind == "pr":
+            return {"loss": out["loss"], "phoneme_logits": out["phoneme_logits"][:, :T], "log_probs": out["log_probs"][:T],
+                    "hidden_states": out["hidden_states"][:, :T]}
+        return {"loss": out["loss"], "mse_loss": out["mse_loss"], "ce_loss": out["ce_loss"], "tvs_pred": out["tvs_pred"][:, :T],
+                "phn_fc_pred": out["phn_fc_pred"][:, :T]}
+
+    def suspend(self) -> None:
+        """Before an EAGER phase on the same model (validation between epochs): un-freeze the model's compute-copy cache so that
+        eager forwards rebuild their copies from the current parameters.  The captured graphs keep their own copies (refreshed by
+        their prep segment on every replay), so the next step() needs nothing."""
+        self.w._cache_mode = None
+        self.w._cache.clear()
+
+    def close(self):
+        for r in self.runners.values():
+            r.close()
+        self.runners = {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
 
 class GraphedForceStep:

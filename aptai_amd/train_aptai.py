@@ -5,7 +5,7 @@
 (SURVEY.md §2 rows marked out of scope) — `SyntheticHPRC` yields items with the fields `_collate_fn` consumes instead.
 
     python -m aptai_amd.train_aptai --model_dir <local wav2vec2 dir> --num_epochs 2 --steps_per_epoch 20 --batch_size 16
-    python -m aptai_amd.train_aptai --random_init base --graphed        # hipGraph segments for fixed-shape batches
+    python -m aptai_amd.train_aptai --random_init base --graphed        # hipGraph segments, one captured runner per length bucket
 """
 from __future__ import annotations
 
@@ -74,11 +74,13 @@ def train(cfg, model, optimizer, lr_scheduler, train_dataloader, valid_dataloade
         model.train()
         for batch_idx, batch_x in enumerate(train_dataloader):
             if getattr(cfg, "graphed", False):
-                # same step as below, replayed as hipGraph segments; needs one batch shape (drop_last + fixed clip length).
-                # The runner takes the collate_fn's HOST batch: pinned staging ring + asynchronous copies (set_batch)
+                # same step as below, replayed as hipGraph segments.  The collate pads every batch to its own longest utterance
+                # (train/train_aptai.py:268-285), so shapes vary: BucketedGraphedStep keeps one captured runner per (batch size,
+                # bucket length) and feeds each batch to the next larger bucket (results equal the eager step on the batch's own
+                # shape).  The runners take the collate_fn's HOST batch: pinned staging ring + asynchronous copies (set_batch)
                 if runner is None:
-                    from .graphed import GraphedAPTAIStep
-                    runner = GraphedAPTAIStep(model, optimizer, {k: v.to(cfg.device) for k, v in batch_x.items()})
+                    from .graphed import BucketedGraphedStep
+                    runner = BucketedGraphedStep(model, optimizer)
                 outputs = runner.step(batch_x)
             else:
                 batch_x = {k: v.to(cfg.device) for k, v in batch_x.items()}
@@ -93,8 +95,7 @@ def train(cfg, model, optimizer, lr_scheduler, train_dataloader, valid_dataloade
                 f"lr: {optimizer.param_groups[0]['lr']:.6f}")
         lr_scheduler.step()
         if runner is not None:
-            runner.close()
-            runner = None
+            runner.suspend()             # the eager validation below rebuilds its weight copies; the captured buckets stay
         model.eval()
         val_logs = validate(model, cfg.device, cfg.vocab, epoch, getattr(cfg, "exp_dir", None), test_spk, valid_dataloader)
         better = (eval_target is None
@@ -108,6 +109,8 @@ def train(cfg, model, optimizer, lr_scheduler, train_dataloader, valid_dataloade
                          saved=bool(better))
         history.append(epoch_log)
         log(f"Epoch {epoch + 1}/{cfg.num_epochs} -> " + " | ".join(f"{k}: {v:.4f}" for k, v in epoch_log.items() if isinstance(v, float)))
+    if runner is not None:
+        runner.close()
     return history
 
 
@@ -249,7 +252,7 @@ def main(argv=None):
         cfg = default_cfg(num_epochs=a.num_epochs, batch_size=a.batch_size, learning_rate=a.learning_rate, graphed=a.graphed,
                           huggingface_model_id=model_dir, pretrain_cfg=w2v)
         model, optimizer, lr_scheduler = load_model_optimizer(cfg)
-    train_ds = SyntheticHPRC(a.steps_per_epoch * a.batch_size, a.seconds, vary_length=not a.graphed, seed=1, cfg=w2v)
+    train_ds = SyntheticHPRC(a.steps_per_epoch * a.batch_size, a.seconds, vary_length=True, seed=1, cfg=w2v)
     val_ds = SyntheticHPRC(a.val_items, a.seconds, vary_length=True, seed=2, cfg=w2v)
     train_dl = torch.utils.data.DataLoader(train_ds, batch_size=a.batch_size, shuffle=True, drop_last=True, collate_fn=hostlogic.collate_aptai)
     val_dl = torch.utils.data.DataLoader(val_ds, batch_size=1, shuffle=False, collate_fn=hostlogic.collate_aptai)

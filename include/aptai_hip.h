@@ -38,6 +38,13 @@ int aptai_device_check(char* name, int name_len);
  * process-global state: two runners / two models on two streams are independent).  The caller keeps the two words alive
  * until it clears the binding. */
 int aptai_set_seed_salt(void* stream, const void* device_ptr_2xu32);
+/* Per-step frame bounds, bound to ONE stream like the salt: device pointer to two int32 words {frames of the first conv layer that
+ * count for its GroupNorm statistics (HF:317-323), frames that exist for LowPassFilterLayer's zero padding (models/modules.py:46-61)};
+ * null clears the binding.  The reference pads every batch to ITS OWN longest utterance (train/train_aptai.py:268-285), and both
+ * operations see that padded length; a hipGraph captured for a longer bucket length replays with the bounds of the batch it is fed
+ * (aptai_conv0_fwd / aptai_conv0_bwd in group mode and aptai_lowpass_fir read them), so it equals the eager run on the batch's
+ * own shape.  The caller keeps the two words alive until it clears the binding. */
+int aptai_set_frame_bounds(void* stream, const void* device_ptr_2xi32);
 
 /* ------------------------------------------------------------------------------------------------ GEMM
  * C[M,N] = A . B^T with fp32 accumulation (MFMA), replacing nn.Linear / nn.Conv1d(k>1 as implicit GEMM):

@@ -263,3 +263,62 @@ def test_graphed_force_step_matches_eager_and_varies_with_dropout():
     b = runner.step(batches[0])["tvs_pred"].clone()
     runner.close()
     assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
+def test_bucketed_graphs_equal_the_eager_loop_on_variable_length_batches():
+    """BucketedGraphedStep: the reference's collate pads every batch to its own longest utterance (train/train_aptai.py:268-285),
+    so consecutive batches have different shapes.  A variable-length synthetic epoch (five batches, three padded lengths, two
+    buckets, host tensors as the collate_fn produces them) through the bucketed graph runner and through the eager loop on the
+    un-bucketed shapes, from the same initial state: same losses, same trajectories on every valid frame, same updated parameters.
+    wav2vec2-base shape: its first conv layer normalises over ALL frames of the padded batch (GroupNorm), the case that needs the
+    per-step frame bounds; the low-pass filter's zero padding is the other."""
+    from aptai_amd import hostlogic
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.graphed import BucketedGraphedStep
+    from aptai_amd.train_aptai import SyntheticHPRC
+    from oracle import synth
+    from test_gpu_aptai import _build
+    cfg = W2V2Config.base(num_hidden_layers=2, hidden_dropout=0., activation_dropout=0., attention_dropout=0.,
+                          feat_proj_dropout=0., final_dropout=0., layerdrop=0., apply_spec_augment=False, vocab_size=46)
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), 0)
+    batches = []
+    for i, sec in enumerate((1.3, 1.9, 1.45, 2.0, 1.3)):
+        ds = SyntheticHPRC(3, sec, vary_length=True, seed=10 + i, cfg=cfg)
+        batches.append(hostlogic.collate_aptai([ds[j] for j in range(3)]))
+    assert len({b["audio_inputs"].shape[1] for b in batches}) >= 3
+    rec = {}
+    for mode in ("eager", "bucketed"):
+        model = _build(cfg, sd, tv_drop=0.0, phn_drop=0.0)
+        model.train()
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
+        out_rec = []
+        if mode == "eager":
+            for b in batches:
+                cb = {k: v.cuda() for k, v in b.items()}
+                opt.zero_grad(set_to_none=True)
+                out = model(0, **cb)
+                out["loss"].backward()
+                opt.step()
+                out_rec.append((out["loss"].item(), out["tvs_pred"].detach().float().cpu(), out["phn_fc_pred"].cpu()))
+        else:
+            with BucketedGraphedStep(model, opt, bucket_samples=[24000, 32000]) as runner:
+                for b in batches:
+                    out = runner.step(b)                               # HOST batch, padded up to its bucket inside
+                    out_rec.append((out["loss"].item(), out["tvs_pred"].detach().float().cpu().clone(), out["phn_fc_pred"].cpu().clone()))
+                assert len(runner.runners) == 2
+                # an eager forward in between (validation) and more steps: the captured buckets survive
+                runner.suspend()
+                model.eval()
+                with torch.no_grad():
+                    model(0, **{k: v.cuda() for k, v in batches[0].items()})
+                model.train()
+                out_rec.append((runner.step(batches[1])["loss"].item(), None, None))
+        rec[mode] = out_rec
+    for i, ((l0, tv0, p0), (l1, tv1, p1)) in enumerate(zip(rec["eager"], rec["bucketed"])):
+        assert abs(l0 - l1) <= 2e-3 * abs(l0), (i, l0, l1)
+        assert tv0.shape == tv1.shape, (tv0.shape, tv1.shape)
+        lens = hostlogic.feat_extract_output_lengths(batches[i]["audio_lengths"], cfg.conv_kernel, cfg.conv_stride)
+        for u, n in enumerate(lens.tolist()):
+            assert (tv0[u, :n] - tv1[u, :n]).abs().max().item() <= 2e-2 * tv0[u, :n].abs().max().item(), (i, u)
+            assert (p0[u, :n] != p1[u, :n]).float().mean().item() <= 0.1, (i, u)       # near-uniform random-init logits: a few bf16 near-ties flip once the two runs' parameters differ in their last bits (4 of 99 frames measured)
+    assert rec["eager"][-1][0] < rec["eager"][0][0] * 1.5
