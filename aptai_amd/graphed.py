@@ -362,6 +362,7 @@ class GraphedAPTAIStep:
             self.set_batch(batch)
         keep = self._host_randomness()
         L = self.cfg.num_hidden_layers
+        self.w._train_marker = getattr(self.w, "_train_marker", 0) + 1     # eval-mode weight copies built before this step are stale
         if self.loss_norm is not None:
             self.loss_norm.begin(self.tv_tgt, self.phn_tgt)      # travels under the encoder forward
         self.g_prep.replay()

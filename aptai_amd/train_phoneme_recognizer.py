@@ -82,6 +82,7 @@ def train(cfg, model, optimizer, lr_scheduler, vocab, train_dataloader, valid_da
     """train/train_phoneme_recognizer.py:384-505.  Returns the per-epoch log dicts."""
     eval_target = None
     history = []
+    runner = None
     best_ckpt_path, last_ckpt_path, all_ckpt_path = Path(best_ckpt_path), Path(last_ckpt_path), Path(all_ckpt_path)
     best_ckpt_path.mkdir(parents=True, exist_ok=True)
     last_ckpt_path.mkdir(parents=True, exist_ok=True)
@@ -97,15 +98,25 @@ def train(cfg, model, optimizer, lr_scheduler, vocab, train_dataloader, valid_da
         for batch_idx, batch_x in enumerate(train_dataloader):
             if batch_idx not in subset_random:
                 continue
-            batch_x = {k: v.to(cfg.device) for k, v in batch_x.items()}
-            optimizer.zero_grad()
-            outputs = model(**batch_x)
-            outputs["loss"].backward()
-            optimizer.step()
+            if getattr(cfg, "graphed", False):
+                # hipGraph replay of the same step; the collate pads each batch to its own longest utterance and label list
+                # (train/train_phoneme_recognizer.py:224-239), so one captured runner per (batch size, length bucket, label width)
+                if runner is None:
+                    from .graphed import BucketedGraphedStep
+                    runner = BucketedGraphedStep(model, optimizer)
+                outputs = runner.step({k: v.to(cfg.device) for k, v in batch_x.items()})
+            else:
+                batch_x = {k: v.to(cfg.device) for k, v in batch_x.items()}
+                optimizer.zero_grad()
+                outputs = model(**batch_x)
+                outputs["loss"].backward()
+                optimizer.step()
             sum_train_loss += float(outputs["loss"].detach())
             log(f"\tepoch {epoch + 1} ~ batch {subset_random_idx + 1}/{epoch_train_steps}, train_loss: {float(outputs['loss'].detach()):.4f}")
             subset_random_idx += 1
         lr_scheduler.step()
+        if runner is not None:
+            runner.suspend()             # the eager validation below rebuilds its weight copies; the captured buckets stay
         model.eval()
         val_logs = validate(model, cfg.device, vocab, epoch, valid_dataloader)
         better = (eval_target is None
@@ -128,6 +139,8 @@ def train(cfg, model, optimizer, lr_scheduler, vocab, train_dataloader, valid_da
         history.append(epoch_log)
         log(f"Epoch {epoch + 1}/{cfg.num_epochs} -> lr: {epoch_log['lr']}| mean_train_loss: {epoch_log['mean_train_loss']}| "
             f"mean_val_loss: {val_logs['mean_val_loss']}| val_per: {val_logs['mean_val_per']}")
+    if runner is not None:
+        runner.close()
     return history
 
 

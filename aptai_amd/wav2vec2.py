@@ -594,7 +594,12 @@ class Wav2Vec2Model(nn.Module):
 
     # ------------------------------------------------------------------ bf16 compute copies of the parameters
     def _versions(self, params):
-        return tuple((p.data_ptr(), p._version) for p in params)
+        # Tensor._version alone is not enough: optimisers with their own kernels (torch's fused Adam, aptai_amd.optim.Adam) update
+        # parameters in place without bumping it.  `_train_marker` counts training steps of this model (every training-mode forward
+        # under autograd, every replayed graph step), so a copy built in eval mode is rebuilt by the first eval forward after any
+        # training step - validation then sees the LAST update, not the copies the last training forward made.
+        # (training-mode forwards do not key on it: trainable copies are rebuilt on every forward there, frozen ones never move)
+        return (0 if self.training else getattr(self, "_train_marker", 0),) + tuple((p.data_ptr(), p._version) for p in params)
 
     def _cached(self, key, params, build):
         mode = getattr(self, "_cache_mode", None)            # graph capture: "build" = always rebuild, "frozen" = always hit
@@ -991,6 +996,8 @@ class Wav2Vec2Model(nn.Module):
         self._step += 1
         seed = _seed(self.base_seed, self._step)
         training = self.training
+        if training and torch.is_grad_enabled():
+            self._train_marker = getattr(self, "_train_marker", 0) + 1
 
         prec = getattr(self, "_encoder_precision", "bf16")
         if prec in ("f32x3", "f32x6") and not training and not torch.is_grad_enabled():

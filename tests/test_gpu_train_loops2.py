@@ -153,3 +153,38 @@ def test_device_best_path_decode_matches_the_host_definition():
         m = min(len(ref), 60)
         assert list(ids[b, :m]) == list(ref[:m]) and (ids[b, m:] == 0).all()
     assert list(ids[2, :n[2]]) == [3] and n[3] > 60
+
+
+def test_phoneme_recognizer_loop_replays_graphs_on_the_reference_collate(tmp_path):
+    """train_phoneme_recognizer.train with cfg.graphed: the reference's collate (per-batch padding of waveforms and label lists,
+    train/train_phoneme_recognizer.py:224-239) feeds BucketedGraphedStep; the trainable conv stack, CTC head and optimiser run as
+    replayed segments.  With the regularisers off the epoch's losses equal the eager loop's from the same initial state."""
+    from aptai_amd import hostlogic, train_phoneme_recognizer as T
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.wav2vec2 import Wav2Vec2Model
+    vocab = T.default_vocab()
+    w2v = W2V2Config.base(num_hidden_layers=2, layerdrop=0.0, hidden_dropout=0., activation_dropout=0., attention_dropout=0.,
+                          feat_proj_dropout=0., apply_spec_augment=False)
+    torch.manual_seed(0)
+    d = tmp_path / "w2v"
+    Wav2Vec2Model(w2v).save_pretrained(str(d))
+    logs = {}
+    for graphed in (False, True):
+        cfg = T.default_cfg(num_epochs=2, batch_size=2, samples_per_epoch=8, learning_rate=2e-5, save_all_epochs=False, final_dropout=0.0,
+                            huggingface_model_id=str(d), pretrain_cfg=w2v, num_warmup_epochs=2, graphed=graphed)
+        torch.manual_seed(3)                                            # pr_head is freshly initialised (not in the wav2vec2 checkpoint)
+        model, opt, sched = T.load_model_optimizer(cfg, vocab)
+        tr = torch.utils.data.DataLoader(T.SyntheticCommonPhone(8, 1.2, len(vocab), seed=1), batch_size=2, drop_last=True,
+                                         collate_fn=hostlogic.collate_pr)
+        va = torch.utils.data.DataLoader(T.SyntheticCommonPhone(2, 1.0, len(vocab), seed=2), batch_size=1, collate_fn=hostlogic.collate_pr)
+        random.seed(7)
+        lines = []
+        sub = tmp_path / ("g" if graphed else "e")
+        hist = T.train(cfg, model, opt, sched, vocab, tr, va, sub / "best", sub / "last", sub / "all", log=lines.append)
+        logs[graphed] = ([float(l.split("train_loss:")[1]) for l in lines if l.startswith("\tepoch")], hist)
+    le, lg = logs[False][0], logs[True][0]
+    assert len(le) == len(lg) == 8
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 5e-3 * abs(a), (le, lg)
+    for he, hg in zip(logs[False][1], logs[True][1]):
+        assert abs(he["mean_val_loss"] - hg["mean_val_loss"]) <= 5e-3 * abs(he["mean_val_loss"])
