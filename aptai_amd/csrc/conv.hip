@@ -6,6 +6,8 @@
 // HBM-bound by the output write (512 ch x 2 B per frame; the waveform read is 20 B per frame).
 // One wave per frame, lane = 8 consecutive channels (16-byte coalesced stores); weights live in registers.
 // Layers 1..6 are strided-row implicit GEMMs (gemm.hip).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -263,6 +265,74 @@ __global__ __launch_bounds__(256) void conv0_group_kernel(Conv0Args a) {
 }
 
 
+// ---- mode 0 pass 2 on the fp32 MATRIX pipe (v_mfma_f32_16x16x4_f32: exact fp32 products, k-ordered fp32 accumulation).
+// conv0_group_kernel above spends ~28 vector issue slots per output, 10 of them conv FMAs; here the 10-tap dot products run as
+// [16 channels] x [12 taps] x [16 frames] MFMA blocks beside the vector pipe, which keeps only the GELU and the packing:
+//   A (16 x 4 per k-step) = folded taps  w'[c][k] = w[c][k] * rstd_c * gamma_c   (k = 10: the folded shift, k = 11: 0)
+//   B (4 x 16 per k-step) = waveform      x~[k][f] = x[5 (t0 + f) + k]            (k = 10: 1.0 for real frames, k = 11: 0)
+//   D[i][f] = pre-activation of channel ch(g, i) at frame t0 + f;  lane (q = lane / 16, f = lane % 16) holds rows 4q .. 4q+3.
+// Channel map ch(g, 4q + r) = 32 (g / 2) + 8 q + 4 (g % 2) + r: the lane's outputs of a PAIR of groups are 8 consecutive
+// channels = one 16-byte store (a store instruction writes 16 rows x 64 B; the next pair completes the 128-byte lines).
+// One wave per 16 frames; the 96 tap registers stay resident, two groups' accumulators are live at a time.
+__global__ __launch_bounds__(256) void conv0_group_mfma_kernel(Conv0Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, f = lane & 15;
+    const int b = blockIdx.y;
+    float wa[32][3];                                     // A operand: row i = f, k = 4 s + q
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+        const int c = 32 * (g >> 1) + 8 * (f >> 2) + 4 * (g & 1) + (f & 3);
+        const float mu = a.stats[((long)b * 2 + 0) * C0 + c], rs = a.stats[((long)b * 2 + 1) * C0 + c];
+        const float sc = rs * a.gamma[c];
+        const float sh = fmaf((a.bias ? a.bias[c] : 0.f) - mu, sc, a.beta[c]);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = 4 * s + q;
+            wa[g][s] = k < KW ? a.w[c * KW + k] * sc : (k == KW ? sh : 0.f);
+        }
+    }
+    const float* xb = a.audio + (long)b * a.S;
+    bf16_t* ob = a.out + (long)b * a.T_alloc * C0;
+    const long last = a.S - 1;
+    const int nblk = a.T_alloc >> 4;                     // T_alloc is a multiple of 64 (product of the later strides)
+    const int step = gridDim.x * 4;
+    auto load_x = [&](int blk, float (&x)[3]) {
+        const int t = blk * 16 + f;
+        const bool real = t < a.T_real;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = 4 * s + q;
+            long idx = (long)t * STRIDE + k;
+            idx = idx < last ? idx : last;               // k >= 10 meets a zero tap: any in-bounds sample will do
+            const float v = xb[real ? idx : 0];
+            x[s] = !real ? 0.f : (k < KW ? v : (k == KW ? 1.0f : 0.f));
+        }
+    };
+    int blk = blockIdx.x * 4 + wave;
+    float xc[3] = {0.f, 0.f, 0.f};
+    if (blk < nblk) load_x(blk, xc);
+    for (; blk < nblk; blk += step) {
+        float xn[3] = {0.f, 0.f, 0.f};
+        if (blk + step < nblk) load_x(blk + step, xn);   // next block's samples under this block's arithmetic
+        bf16_t* orow = ob + (long)(blk * 16 + f) * C0 + 8 * q;
+#pragma unroll
+        for (int gp = 0; gp < 16; ++gp) {
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2 * gp][s], xc[s], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[2 * gp + 1][s], xc[s], d1, 0, 0, 0);
+            }
+            const f32x2 g0 = gelu_fast2((f32x2){d0[0], d0[1]}), g1 = gelu_fast2((f32x2){d0[2], d0[3]});
+            const f32x2 g2 = gelu_fast2((f32x2){d1[0], d1[1]}), g3 = gelu_fast2((f32x2){d1[2], d1[3]});
+            *(u32x4*)(orow + 32 * gp) = (u32x4){pack2bf(g0.x, g0.y), pack2bf(g1.x, g1.y), pack2bf(g2.x, g2.y), pack2bf(g3.x, g3.y)};
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) xc[s] = xn[s];
+    }
+}
+
+
 // ====================================================================================== backward of layer 0
 // The conv output is never stored: every pass recomputes it from the waveform (10 MACs/output) and fuses GELU', the
 // norm backward and the weight-gradient accumulation.  Weight/affine gradients are reduced deterministically:
@@ -515,6 +585,22 @@ extern "C" int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const f
     APTAI_LAUNCH(conv0_moments_final_kernel, dim3((unsigned)B), dim3(C0), 0, stream, (const float*)a.partials, weight, bias,
                  stats, nch, (int)T_real, eps, (const int*)aptai_frame_bounds(stream_));
     APTAI_CHECK_LAUNCH("conv0_moments_final_kernel");
+    // the conv on the fp32 matrix pipe beside the vector pipe's GELU (APTAI_CONV0_MFMA=0: the all-vector kernel, A/B)
+    static int use_mfma = -1;
+    if (use_mfma < 0) {
+        const char* e = getenv("APTAI_CONV0_MFMA");
+        use_mfma = e ? atoi(e) : 1;
+    }
+    if (use_mfma && T_alloc % 16 == 0) {
+        // ~two rounds of the 768 block slots (3 blocks per CU at 145 registers), each wave amortising its 96 tap registers over
+        // several 16-frame blocks
+        long mb = ceil_div(1536, B);
+        const long mb_max = ceil_div(T_alloc / 16, 4);
+        if (mb > mb_max) mb = mb_max;
+        APTAI_LAUNCH(conv0_group_mfma_kernel, dim3((unsigned)mb, (unsigned)B), dim3(256), 0, stream, a);
+        APTAI_CHECK_LAUNCH("conv0_group_mfma_kernel");
+        return APTAI_OK;
+    }
     APTAI_LAUNCH(conv0_group_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, stream, a);
     APTAI_CHECK_LAUNCH("conv0_group_kernel");
     return APTAI_OK;
