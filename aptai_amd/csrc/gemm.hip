@@ -34,6 +34,9 @@ constexpr int SMEM_BYTES = BM * EPI_PITCH > 2 * STAGE_BYTES ? BM * EPI_PITCH : 2
 #ifndef APTAI_GEMM_M64_ASM
 #define APTAI_GEMM_M64_ASM 1
 #endif
+#ifndef APTAI_GEMM192_ASM
+#define APTAI_GEMM192_ASM 1
+#endif
 constexpr int RING_HALF_BYTES = (BM + BN) * 32 * 2;    // 16 KiB: 32 k-rows of both operands
 constexpr int SMEM_RING_BYTES = 5 * RING_HALF_BYTES;   // 80 KiB: two blocks per CU use all of the 160 KiB
 static_assert(SMEM_RING_BYTES >= BM * EPI_PITCH, "the epilogue tile must fit the ring");
@@ -1258,6 +1261,82 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (!A_KM && B_KM && APTAI_GEMM192_ASM) {
+        // dgrad layout (A K-contiguous, B K-major): every LDS read through inline asm with counted waits.  Behind an LDS-DMA the
+        // compiler puts `s_waitcnt vmcnt(0)` in front of each ds_read_tr builtin (section "asm transposing reads" of the 128-tile
+        // kernel), which drains this kernel's three-stage ring at every K-tile: the builtin form ran at the speed of the 64-row
+        // tiles, so the tile rule never picked it.  One read_half = 4 ds_read_b128 (A) + 6 ds_read_b64_tr_b16 (B) = 10 LDS
+        // operations, returned in order: `lgkmcnt(10)` = "everything but the newest half is back".
+        u32x4 aa[2][4];
+        short4v bl[2][3], bh[2][3];
+        auto read_half = [&](int slot, int ks) {
+            const char* sa = smem + slot * T3_STAGE;
+            const char* sb = sa + T3_A_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + (lane & 15), q = ks * 4 + (lane >> 4);
+                const uint32_t addr = lds_u32(sa) + (uint32_t)(row * 128 + ((q ^ (row & 7)) << 4));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(aa[ks][i]) : "v"(addr));
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int row_base = wn * 48 + j * 16;
+                const char* panel = sb + (row_base >> 6) * 8192;
+                const int rb = row_base & 63;
+                const int gq = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+                const int ch = (rb >> 3) + (pp >> 1);
+                const int sub = (pp & 1) << 3;
+                const int k_lo = ks * 32 + gq * 8 + qq, k_hi = k_lo + 4;
+                const uint32_t a0 = lds_u32(panel) + (uint32_t)(k_lo * 128 + ((ch ^ pn_swz(k_lo)) << 4) + sub);
+                const uint32_t a1 = lds_u32(panel) + (uint32_t)(k_hi * 128 + ((ch ^ pn_swz(k_hi)) << 4) + sub);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bl[ks][j]) : "v"(a0));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(bh[ks][j]) : "v"(a1));
+            }
+        };
+        auto mfma_half = [&](int ks) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(combine_tr(bl[ks][j], bh[ks][j]), __builtin_bit_cast(bf16x8, aa[ks][i]),
+                                                                        acc[i][j], 0, 0, 0);
+        };
+#define APTAI_TIE_HALF(K) "+v"(aa[K][0]), "+v"(aa[K][1]), "+v"(aa[K][2]), "+v"(aa[K][3]), "+v"(bl[K][0]), "+v"(bl[K][1]), "+v"(bl[K][2]), \
+                          "+v"(bh[K][0]), "+v"(bh[K][1]), "+v"(bh[K][2])
+        if (nk > 0) {
+            stage(0);
+            if (nk > 1) stage(1);
+            if (nk > 2) stage(2);
+            if (nk > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (nk > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            read_half(0, 0);
+            read_half(0, 1);
+        }
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            asm volatile("s_waitcnt lgkmcnt(10)" : APTAI_TIE_HALF(0));          // half 0 of this K-tile is back; half 1 may be in flight
+            mfma_half(0);
+            if (kt + 1 < nk) {
+                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 3 < nk) stage(cur);
+                asm volatile("" : APTAI_TIE_HALF(1));                            // half 1 completed at the wait above: MFMAs stay below it
+                read_half(nxt, 0);
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : APTAI_TIE_HALF(1));
+            }
+            mfma_half(1);
+            if (kt + 1 < nk) read_half(nxt, 1);
+            cur = nxt;
+        }
+#undef APTAI_TIE_HALF
+    } else {
     bf16x8 af[2][4], bfr[2][3];
     auto read_half = [&](int slot, int ks) {
         const char* sa = smem + slot * T3_STAGE;
@@ -1302,6 +1381,7 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
         mfma_half(1);
         if (kt + 1 < nk) read_half(nxt, 1);
         cur = nxt;
+    }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1515,7 +1595,9 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
         // 128x192 tiles (one block per CU): measured faster than the 128-tile kernel only where the whole K-contiguous GEMM
         // is ONE round of full tiles (8192 x 768: 16.9 vs 19.7 us at K = 768, 43.6 vs 51.2 us at K = 3072)
         const long t192 = ceil_div(d->M, T3_BM) * ceil_div(d->N, T3_BN) * nbatch * nsplit;
-        if (tile == 128 && !d->a_kmajor && !d->b_kmajor && d->M % T3_BM == 0 && d->N % T3_BN == 0 && t192 > 192 && t192 <= 256)
+        // (round 3: also with a K-major B, the dgrads [8192] x 768 - since its LDS reads go through inline asm with counted waits the
+        //  192-tile kernel no longer drains its ring at every K-tile: 35.6 vs 38.6 us at K = 2304, 45.1 vs 49.0 us at K = 3072)
+        if (tile == 128 && !d->a_kmajor && d->M % T3_BM == 0 && d->N % T3_BN == 0 && t192 > 192 && t192 <= 256)
             tile = 192;
         // ... and where it is a whole number of rounds with a light epilogue (one block per CU leaves GELU / dropout arithmetic
         // exposed: 8192 x 2304 x 768 with bias only 38.3 vs 40.7-42.8 us for the 64- / 128-row tiles, but 58.0 vs 52.5 us with

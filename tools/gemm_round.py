@@ -31,9 +31,11 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g).to(torch.bfloat16)
     print("layout shape tile: plain us (TF/s) | heavy epilogue us")
-    shapes = ((3072, 768), (2304, 768), (768, 768), (768, 3072), (2048, 768), (2048, 3072), (1024, 768))
+    shapes = ((3072, 768), (2304, 768), (768, 768), (768, 3072), (768, 2304), (2048, 768), (2048, 3072), (1024, 768))
     if len(sys.argv) > 1 and sys.argv[1] == "short":
         shapes = shapes[:4]
+    if len(sys.argv) > 1 and sys.argv[1] == "dgrad":
+        shapes = ((768, 768), (768, 2304), (768, 3072), (3072, 768))
     for (n, k) in shapes:
         for km in (False, True):
             a = rnd(M, k)
@@ -42,7 +44,7 @@ def main():
             res = rnd(M, n)
             pre = torch.empty(M, n, device="cuda", dtype=torch.bfloat16)
             for tile in (0, 257, 256, 128, 192, 64):
-                if tile == 192 and (n % 192 or km):
+                if tile == 192 and n % 192:
                     continue
                 try:
                     t = bench(lambda: ops.gemm(a, b, M, n, k, b_kmajor=km, tile=tile))
