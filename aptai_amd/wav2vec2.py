@@ -28,6 +28,16 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def _rows_with_zero_slack(rows: int, C: int, dev, slack: int = 8) -> torch.Tensor:
+    """[rows][C] bf16 whose last `slack` rows are zero and whose other rows are about to be written whole by a kernel: the
+    overlapping-row GEMM of the next conv layer (and the dgrad accumulation of the previous one) reads a few rows past the last
+    utterance, and 0 x NaN must not reach a weight gradient.  A full torch.zeros of these buffers (up to 537 MB each, ~20 per
+    Wav2Vec2_PR step) cost 0.39 ms per step (rocprofv3, profiles/r03_pr_kernel_stats.csv)."""
+    t = torch.empty((rows, C), device=dev, dtype=torch.bfloat16)
+    t[rows - slack:].zero_()
+    return t
+
+
 class _Holder(nn.Module):
     """Parameter container (the arithmetic lives in the HIP kernels, not in module forwards)."""
 
@@ -743,7 +753,7 @@ class Wav2Vec2Model(nn.Module):
         def new_buf(i, rows):
             # frozen path: persistent scratch (its slack rows were zeroed once); trainable path: fresh buffers (saved)
             if save:
-                return torch.zeros((rows, C), device=dev, dtype=torch.bfloat16)
+                return _rows_with_zero_slack(rows, C, dev)
             if i == len(cl) - 1:          # the features outlive this call (saved by the projection's backward): own storage
                 return torch.empty((rows, C), device=dev, dtype=torch.bfloat16)
             return self._scratch(("conv", i, rows), rows * C, dev).view(rows, C)
@@ -761,7 +771,7 @@ class Wav2Vec2Model(nn.Module):
             out = new_buf(i, Mi + 8)
             bias = cl[i].conv.bias if cfg.conv_bias else None
             if layer_mode:
-                u = torch.zeros((Mi + 8, C), device=dev, dtype=torch.bfloat16) if save else out
+                u = _rows_with_zero_slack(Mi + 8, C, dev) if save else out
                 ops.gemm(buf, ws[i - 1], Mi, C, k * C, lda=s * C, out=u, ldc=C, bias=bias)
                 _, m, r = ops.layernorm_fwd(u[:Mi], cl[i].layer_norm.weight, cl[i].layer_norm.bias, 1e-5, gelu_after=True,
                                             save_stats=save, out=out[:Mi])
@@ -769,7 +779,7 @@ class Wav2Vec2Model(nn.Module):
                     sv.pre.append(u)
                     sv.stats.append((m, r))
             else:
-                u = torch.zeros((Mi + 8, C), device=dev, dtype=torch.bfloat16) if save else None
+                u = _rows_with_zero_slack(Mi + 8, C, dev) if save else None
                 ops.gemm(buf, ws[i - 1], Mi, C, k * C, lda=s * C, out=out, ldc=C, bias=bias, gelu=True, out_pre=u)
                 if save:
                     sv.pre.append(u)
@@ -809,7 +819,7 @@ class Wav2Vec2Model(nn.Module):
             dw = ops.gemm(du, x_in, C, k * C, Mi, a_kmajor=True, b_kmajor=True, out_f32=True, ldb=s * C, split_k=sk)
             grads[(i, "w")] = dw.view(C, k, C).permute(0, 2, 1).contiguous()          # [N][kw][c] -> nn.Conv1d's [N][c][kw]
             # ---- dgrad into the output of layer i-1
-            dx = torch.zeros((g.B * g.alloc[i - 1] + 8, C), device=dev, dtype=torch.bfloat16)
+            dx = _rows_with_zero_slack(g.B * g.alloc[i - 1] + 8, C, dev)
             fuse = (not layer_mode) and (i - 1 >= 1)         # base: fold gelu'(u_{i-1}) into the epilogue
             aux = sv.pre[i - 1] if fuse else None
             ops.gemm(du, ws[i - 1], Mi, s * C, C, b_kmajor=True, ldb=k * C, out=dx, ldc=s * C, dgelu_aux=aux,
