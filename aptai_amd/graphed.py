@@ -330,13 +330,36 @@ class GraphedAPTAIStep:
         if self.fin is not None:
             self.grads[w.encoder.layer_norm.weight], self.grads[w.encoder.layer_norm.bias] = fin_grads
 
-        # -- layers backward (reverse capture order = replay order)
+        # -- layers backward (reverse capture order = replay order).  APTAI_WGRAD_OVERLAP=1 (experiment, OFF by default): the layer's
+        # grouped weight-gradient launch as its own graph, replayed on a side stream beside the NEXT layer's dgrad chain (nothing
+        # downstream reads it before the optimiser), hoping its 486 tiles fill the launch gaps and one-round tails of the ~12
+        # dependent kernels of that chain.  Measured on one box, interleaved: 9.57 / 9.57 ms inline vs 9.93 / 9.97 ms overlapped -
+        # two chip-filling launches at once evict each other's operand panels from L2 and lose more than the gaps they fill.
+        # (The tensors the side graph reads stay referenced in `self._wpending`, so the shared graph pool never hands their memory
+        # to a later segment.)
         self.g_bwd = [None] * L
+        self.g_bww = [None] * L
+        self._wpending = [None] * L
         self.layer_grads = [None] * L
+        self.overlap_wgrad = (os.environ.get("APTAI_WGRAD_OVERLAP", "0") != "0") and self.group_reducer is None
+        self._w_stream = torch.cuda.Stream(device=self.dev) if self.overlap_wgrad else None
         for i in range(L - 1, -1, -1):
             gr = mk()
-            with torch.cuda.graph(gr, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
-                dx, pg = self.impl[i].bwd(self.s_layer[i], (self.dX[i + 1],), True)
+            if self.overlap_wgrad:
+                with torch.cuda.graph(gr, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
+                    res = self.impl[i].bwd(self.s_layer[i], (self.dX[i + 1],), True, defer_wgrad=True)
+                if len(res) == 3:
+                    dx, ln_grads, self._wpending[i] = res
+                    gw = mk()
+                    with torch.cuda.graph(gw, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
+                        wg = self.impl[i].bwd_wgrad(self._wpending[i])
+                    self.g_bww[i] = gw
+                    pg = tuple(ln_grads) + tuple(wg)
+                else:                                   # APTAI_GROUPED_WGRAD=0: nothing to defer
+                    dx, pg = res
+            else:
+                with torch.cuda.graph(gr, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
+                    dx, pg = self.impl[i].bwd(self.s_layer[i], (self.dX[i + 1],), True)
             self.g_bwd[i] = gr
             self.dX[i] = dx
             self.layer_grads[i] = list(zip(self.lparams[i], pg))
@@ -378,14 +401,21 @@ class GraphedAPTAIStep:
         self.g_tail.replay()
         if red is not None:
             red.launch("heads", [gt for p, gt in self.grads.items() if p.requires_grad and any(p is q for q in self.hparams)])
+        cur = torch.cuda.current_stream(self.dev) if self.overlap_wgrad else None
         for i in range(L - 1, -1, -1):
             if keep[i]:
                 self.g_bwd[i].replay()
+                if self.g_bww[i] is not None:  # the layer's weight gradients on the side stream, beside layer i-1's dgrad chain
+                    self._w_stream.wait_stream(cur)
+                    with torch.cuda.stream(self._w_stream):
+                        self.g_bww[i].replay()
                 if red is not None:            # layer i's gradients travel while layer i-1's backward runs
                     red.launch(("layer", i), self._layer_grad_tensors(i))
             else:
                 self.dX[i].copy_(self.dX[i + 1])
         self.g_front_bwd.replay()
+        if self.overlap_wgrad:
+            cur.wait_stream(self._w_stream)    # every weight gradient is in place before the optimiser reads it
         if red is not None:
             red.launch("front", [gt for p, gt in self.grads.items() if p.requires_grad and not any(p is q for q in self.hparams)])
             red.finish()

@@ -224,9 +224,11 @@ class _LayerImpl:
         y = s2 if pre else ops.layernorm_fwd(s2, ln2w, ln2b, cfg.layer_norm_eps, save_stats=False)[0]
         return (y,), None
 
-    def bwd(self, s, grads, x_needs):
+    def bwd(self, s, grads, x_needs, defer_wgrad=False):
         """dgrad chain on the caller's stream; the weight/bias gradients are independent of that chain and can go to a side
-        stream (APTAI_SIDE_STREAM=1).  Off by default: each GEMM already fills the 256 CUs, the A/B was neutral."""
+        stream (APTAI_SIDE_STREAM=1).  Off by default: each GEMM already fills the 256 CUs, the A/B was neutral.
+        defer_wgrad (graph runner): return (dx, (LayerNorm grads, None), pending) WITHOUT the layer's grouped weight-gradient
+        launch; `bwd_wgrad(pending)` issues it - the runner replays it on a side stream beside the NEXT layer's backward."""
         cfg, g, w = self.cfg, self.g, self.w
         M, H, I = g.M, cfg.hidden_size, cfg.intermediate_size
         heads = cfg.num_attention_heads
@@ -290,6 +292,10 @@ class _LayerImpl:
             dx, _, dg1, db1 = ops.layernorm_bwd(dn1, s.x, s.m1, s.r1, ln1w, dres=ds1)
         else:
             dx = ops.gemm(dqkv, w.wqkv, M, H, 3 * H, b_kmajor=True, residual=ds1)
+        if grouped and defer_wgrad:
+            pending = SimpleNamespace(d_ffn_out=d_ffn_out, hact=s.hact, du=du, ffn_in=ffn_in, d_att_out=d_att_out, ctx=s.ctx, dqkv=dqkv,
+                                      attn_in=attn_in, M=M, H=H, I=I)
+            return dx, (dg1, db1, dg2, db2), pending
         if grouped:
             # all weight and bias gradients of the layer in ONE launch (aptai_gemm_bf16_grouped): 4 x (dY^T X) + 4 x (1^T dY),
             # 432 + 54 full-K tiles for wav2vec2-base = one round of the 512 block slots, no split-K slabs, no reduce kernels
@@ -304,6 +310,23 @@ class _LayerImpl:
         main.wait_stream(side)
         return dx, (dg1, db1, dg2, db2, dwqkv[0:H], dwqkv[H:2 * H], dwqkv[2 * H:3 * H], dbqkv[0:H], dbqkv[H:2 * H],
                     dbqkv[2 * H:3 * H], dwo, dbo, dw1, dbias1, dw2, dbias2)
+
+
+    @staticmethod
+    def bwd_wgrad(p):
+        """The grouped weight / bias gradient launch of one layer from the tensors its dgrad chain left behind (see bwd).  Returns
+        the 12 Linear-parameter gradients in the order of bwd's tuple (after the four LayerNorm gradients)."""
+        M, H, I = p.M, p.H, p.I
+        tn = dict(a_kmajor=True, b_kmajor=True, out_f32=True)
+        ones = ops.ones_kmajor(M, p.du.device)
+        dw2, dw1, dwo, dwqkv, r2, r1, ro, rq = ops.gemm_grouped([
+            (p.d_ffn_out, p.hact, H, I, M, tn), (p.du, p.ffn_in, I, H, M, tn), (p.d_att_out, p.ctx, H, H, M, tn),
+            (p.dqkv, p.attn_in, 3 * H, H, M, tn),
+            (ones, p.d_ffn_out, 8, H, M, tn), (ones, p.du, 8, I, M, tn), (ones, p.d_att_out, 8, H, M, tn),
+            (ones, p.dqkv, 8, 3 * H, M, tn)])
+        dbias2, dbias1, dbo, dbqkv = r2[0], r1[0], ro[0], rq[0]
+        return (dwqkv[0:H], dwqkv[H:2 * H], dwqkv[2 * H:3 * H], dbqkv[0:H], dbqkv[H:2 * H], dbqkv[2 * H:3 * H], dwo, dbo, dw1, dbias1,
+                dw2, dbias2)
 
 
 _SIDE_STREAMS = {}
