@@ -120,7 +120,10 @@ class GraphedAPTAIStep:
         model.zero_grad(set_to_none=True)
         (model(**batch) if self.kind == "pr" else model(0, **batch))["loss"].backward()
         model.zero_grad(set_to_none=True)
-        self._capture()
+        try:
+            self._capture()
+        finally:
+            ops.ln_defer_end()                 # whatever happened during capture, eager LayerNorm backwards reduce their own partials again
 
     # ------------------------------------------------------------------ inputs
     def set_batch(self, batch: Dict[str, torch.Tensor]) -> None:
@@ -308,6 +311,10 @@ class GraphedAPTAIStep:
             self.loss_norm = getattr(model, "dp_loss_norm", None)
             if self.loss_norm is not None:
                 self.st_heads.norm_scalars = self.loss_norm.buffer(self.dev)
+        # single GPU: the ~24 LayerNorm parameter-gradient reductions of the backward pass (one 4.8 us launch + a kernel boundary each)
+        # are collected here and replayed as ONE launch behind the front-end backward; nothing reads them before the optimiser.
+        # Data parallel keeps them per call: a layer's gradients leave for the all-reduce right after its segment.
+        self._ln_jobs = ops.ln_defer_begin() if (self.group_reducer is None and os.environ.get("APTAI_LN_DEFER", "1") != "0") else None
         self.g_tail = mk()
         with torch.cuda.graph(self.g_tail, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
             hl = self.X[L]
@@ -374,6 +381,16 @@ class GraphedAPTAIStep:
                 self.grads[p] = gt
         for p, gt in zip(w._conv_params(), conv_grads):
             self.grads[p] = gt
+        self.g_ln = None
+        if self._ln_jobs is not None:
+            ops.ln_defer_end()
+            if self._ln_jobs:
+                torch.cuda.synchronize()
+                self._ln_table, n_jobs, max_cols = ops.ln_defer_table(self._ln_jobs)        # host-to-device copy: outside capture
+                torch.cuda.synchronize()
+                self.g_ln = mk()
+                with torch.cuda.graph(self.g_ln, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
+                    ops.ln_finalize_multi(self._ln_table, n_jobs, max_cols)
         # the graphs hold raw addresses of the compute copies in the model's cache: keep them alive for this runner's lifetime (a
         # second runner of the same model - another shape bucket - clears and rebuilds the cache for its own capture)
         self._keep_cache = dict(w._cache)
@@ -414,6 +431,8 @@ class GraphedAPTAIStep:
             else:
                 self.dX[i].copy_(self.dX[i + 1])
         self.g_front_bwd.replay()
+        if self.g_ln is not None:
+            self.g_ln.replay()                 # every LayerNorm dgamma / dbeta of the step in one launch
         if self.overlap_wgrad:
             cur.wait_stream(self._w_stream)    # every weight gradient is in place before the optimiser reads it
         if red is not None:

@@ -310,6 +310,35 @@ def layernorm_fwd(x, gamma, beta, eps, *, gelu_after=False, save_stats=True, out
     return y, mean, rstd
 
 
+_LN_DEFER = None      # list of (workspace, dgamma, dbeta, blocks, cols) while a graph runner collects the parameter-gradient reductions
+
+
+def ln_defer_begin() -> list:
+    """From here on layernorm_bwd only writes its per-block partials and registers the reduction; ln_finalize_multi() runs them all in
+    ONE launch (aptai_layernorm_bwd_finalize_multi).  Used by the graph runner around the capture of its backward segments: the
+    returned dgamma / dbeta tensors are filled by that launch, which the runner replays at the end of the backward pass."""
+    global _LN_DEFER
+    _LN_DEFER = []
+    return _LN_DEFER
+
+
+def ln_defer_end() -> None:
+    global _LN_DEFER
+    _LN_DEFER = None
+
+
+def ln_defer_table(jobs: list):
+    """Device job table of the registered reductions (build it OUTSIDE stream capture: it is a host-to-device copy); the caller
+    keeps it, and the job list (workspaces, outputs), alive for as long as it launches ln_finalize_multi on it."""
+    rows = [[ws.data_ptr(), dg.data_ptr(), db.data_ptr(), blocks, cols] for ws, dg, db, blocks, cols in jobs]
+    return torch.tensor(rows, dtype=torch.int64).to(jobs[0][0].device), len(rows), max(r[4] for r in rows)
+
+
+def ln_finalize_multi(table, n: int, max_cols: int) -> None:
+    """Every registered dgamma / dbeta reduction in ONE launch (aptai_layernorm_bwd_finalize_multi); capturable."""
+    _lib.call("aptai_layernorm_bwd_finalize_multi", table.data_ptr(), n, max_cols, _stream())
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, *, dres=None, dropout_p=0.0, seed=0, need_param_grads=True, beta_gelu=None):
     """Returns (dx, dx_drop | None, dgamma | None, dbeta | None)."""
     _dev(dy, x, mean, rstd, gamma, dres)
@@ -320,10 +349,14 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dres=None, dropout_p=0.0, seed=0,
     if need_param_grads:
         dgamma = torch.empty(cols, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(cols, device=x.device, dtype=torch.float32)
-    ws = _ws(_lib.lib().aptai_layernorm_bwd_workspace_bytes(rows, cols), x.device)
+    nbytes = _lib.lib().aptai_layernorm_bwd_workspace_bytes(rows, cols)
+    ws = _ws(nbytes, x.device)
+    defer = need_param_grads and _LN_DEFER is not None
     _lib.call("aptai_layernorm_bwd", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-              _ptr(dres), dx.data_ptr(), _ptr(dx_drop), dropout_p, seed, _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), rows,
-              cols, _ptr(beta_gelu), _stream())
+              _ptr(dres), dx.data_ptr(), _ptr(dx_drop), dropout_p, seed, None if defer else _ptr(dgamma), None if defer else _ptr(dbeta),
+              ws.data_ptr(), rows, cols, _ptr(beta_gelu), _stream())
+    if defer:
+        _LN_DEFER.append((ws, dgamma, dbeta, nbytes // (8 * cols), cols))
     return dx, dx_drop, dgamma, dbeta
 
 

@@ -152,6 +152,10 @@ int aptai_layernorm_bwd(const void* dy, const void* x, const float* mean, const 
                         float* dbeta, void* workspace, int64_t rows, int64_t cols, const float* beta_if_gelu_after,
                         void* stream);   /* beta_if_gelu_after != null: dy is the gradient of gelu(LN(x)) (conv stack, HF:299) */
 int64_t aptai_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
+/* The dgamma / dbeta reductions of MANY aptai_layernorm_bwd calls (each called with dgamma = dbeta = null, its workspace kept) in one
+ * launch: table_dev = device int64 [njobs][5] = {workspace of that call, dgamma | 0, dbeta | 0, blocks = workspace_bytes / (8 * cols),
+ * cols}; max_cols = the widest job.  Replaces the per-call finalisation behind nn.LayerNorm's parameter gradients (HF:587-601). */
+int aptai_layernorm_bwd_finalize_multi(const int64_t* table_dev, int64_t njobs, int64_t max_cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ attention
  * softmax(Q K^T * scale + key-padding mask) V per head (head_dim 64), flash-style, replacing HF:452-461 / sdpa
