@@ -93,6 +93,8 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // fragment loads / accumulator stores touch 32-64 cache lines per instruction)
 constexpr int OUT_PITCH = 144;                                  // bytes per staged row (128 + 16: odd number of 16-B units)
 constexpr int STAGE_BYTES = 4 * 32 * OUT_PITCH;                 // 18 432 B: 32 rows per wave
+constexpr int DKDV_BLOCKS = 3;                                  // dK/dV kernel, pre-scaled Q (the model's path): blocks per CU (register budget 168)
+constexpr int DKDV_KV_BYTES = 2 * 128 * 128;                    // its resident K and V tiles
 
 // [128 rows][64] bf16 (row stride ld elements) -> LDS tile layout (tile_off), 8 lanes per 128-byte row
 __device__ __forceinline__ void stage_rows128(char* dst, const bf16_t* src, long ld, int tid) {
@@ -373,11 +375,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 // accumulators START at -lse2 and -delta (read from LDS straight into the MFMA C operand: no instruction), which removes the
 // FMA in front of every exponential and the subtraction behind every dP.
 template <bool PRE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES + 384];   // staging; Q tile, dO tile (32 queries each)
+__global__ __launch_bounds__(256, PRE ? DKDV_BLOCKS : 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
+    // the block's K and V tiles (128 keys) stay in LDS and their fragments are re-read per query tile: holding them in registers
+    // (32 VGPRs) put the kernel at 206 VGPRs = 2 blocks per CU = 512 slots for the 768 blocks of B = 16, Tp = 512: two rounds, the
+    // second half empty.  At <= 168 VGPRs all 768 blocks are resident at once.
+    __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES + 384 + DKDV_KV_BYTES];   // staging; Q tile, dO tile (32 queries each)
     char* sQ = smem;
     char* sD = smem + 32 * 128;
     float* sL = (float*)(smem + STAGE_BYTES);           // [0,32) lse2, [32,64) delta, [64,96) dropout row hash of the tile's queries
+    char* sKall = smem + STAGE_BYTES + 384;
+    char* sVall = sKall + 128 * 128;
     if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     int tile_x, hd, b;
@@ -401,18 +408,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         return;
     }
     const LaneOffs lo = lane_offs(lane);
-    // K and V fragments of the block's 128 keys through LDS (whole 128-byte rows per 8 lanes)
-    bf16x8 kf[4], vf[4];
     const bf16_t* K0 = a.qkv + (rowbase + kb0) * a.ld + a.H + hd * HD;
-    stage_rows128(smem, K0, a.ld, tid);
-    __syncthreads();
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) kf[ds] = rd_row(smem, lo, wave, ds);
-    __syncthreads();
-    stage_rows128(smem, K0 + a.H, a.ld, tid);
-    __syncthreads();
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) vf[ds] = rd_row(smem, lo, wave, ds);
+    stage_rows128(sKall, K0, a.ld, tid);
+    stage_rows128(sVall, K0 + a.H, a.ld, tid);
     // (the tile loop opens with a barrier before it overwrites the staging area)
     f32x16 dKT[2], dVT[2];
     dKT[0] = dKT[1] = dVT[0] = dVT[1] = (f32x16)(0.f);
@@ -465,12 +463,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 for (int rr = 0; rr < 4; ++rr) { cs[4 * g4 + rr] = l4[rr]; cd[4 * g4 + rr] = d4[rr]; }
             }
         }
-        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sQ, lo, 0, 0), kf[0], cs, 0, 0, 0);
-        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sD, lo, 0, 0), vf[0], cd, 0, 0, 0);
+        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sQ, lo, 0, 0), rd_row(sKall, lo, wave, 0), cs, 0, 0, 0);
+        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sD, lo, 0, 0), rd_row(sVall, lo, wave, 0), cd, 0, 0, 0);
 #pragma unroll
         for (int ds = 1; ds < 4; ++ds) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sQ, lo, 0, ds), kf[ds], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sD, lo, 0, ds), vf[ds], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sQ, lo, 0, ds), rd_row(sKall, lo, wave, ds), s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd_row(sD, lo, 0, ds), rd_row(sVall, lo, wave, ds), dp, 0, 0, 0);
         }
         float pd[16], dsv[16];                                 // P and dS / dscale (see below); dsv starts as delta (!PRE)
         if (PRE) {
@@ -498,6 +496,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const u32x4 rh = *(const u32x4*)((const uint32_t*)sL + 64 + 8 * g4 + 4 * h);
+                // -delta of the rows again from LDS: keeping the 16 registers of the MFMA's C operand alive to here costs the
+                // third block per CU
+                f32x4 nd4 = (f32x4)(0.f);
+                if (PRE) nd4 = *(const f32x4*)(sL + 32 + 8 * g4 + 4 * h);
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int r = 4 * g4 + rr;
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
                     const float p0 = pd[r];
                     // dS = dscale * P (keep * dP - delta / dscale), P_drop = dscale * keep * P: the dQ kernel left delta / dscale
                     // in a.delta and the 1/(1-p) factors are applied once to dK and dV in the epilogue
-                    if (PRE) dsv[r] = p0 * (k ? dp[r] : cd[r]);          // dp = dP - delta already; a dropped element keeps -delta
+                    if (PRE) dsv[r] = p0 * (k ? dp[r] : nd4[rr]);        // dp = dP - delta already; a dropped element keeps -delta
                     else dsv[r] = p0 * ((k ? dp[r] : 0.f) - dsv[r]);
                     pd[r] = k ? p0 : 0.f;
                 }
