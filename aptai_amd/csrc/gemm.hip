@@ -83,17 +83,58 @@ __device__ __forceinline__ void gelu_fast_both(float x, float& y, float& dy) {
 // the pre-activation (or, with EPI_PRE_DGELU, of dropmask * gelu'(pre-activation): the factor the backward multiplies by,
 // so the dgrad epilogue is ONE multiply per element instead of a dropout hash and a gelu'), GELU, dropout, x gelu'(aux) or
 // x aux, + residual, packed 16-byte store.
-__device__ __forceinline__ void epilogue_chunk(float (&v)[8], const GemmArgs& g, const int flags, const long m, const int n,
+//
+// The flag word.  Measured with in-kernel stamps (tools/gemm256_stamps.py): with the flags tested at RUN time this function is ~100
+// issued instructions and ~15 scalar branches per 8 outputs, and a 256 x 256 tile's epilogue took 7.5 us of 27 us at K = 768 with NO
+// option set.  So the epilogues branch ONCE per block (epi_dispatch, block-uniform) into a body compiled for the exact flag word of the
+// launch - the words the model's own launches use are listed there - and everything else runs the run-time form (FM = -1).  The word is
+// the descriptor's flags plus two internal bits for what the descriptor says with pointers / counts.
+constexpr int EPX_PRE = 1 << 16;                               // out_pre != nullptr
+constexpr int EPX_CS = 1 << 17;                                // colscale_n > 0
+__device__ __forceinline__ int epi_flag_word(const GemmArgs& g) {
+    return g.flags | (g.out_pre ? EPX_PRE : 0) | (g.colscale_n > 0 ? EPX_CS : 0);
+}
+template <int FM> struct EpiWord { static constexpr int value = FM; };
+template <class F>
+__device__ __forceinline__ void epi_dispatch(const int fx, F&& f) {
+#define APTAI_EPI_CASE(W)               \
+    if (fx == (W)) {                     \
+        f(EpiWord<(W)>{});               \
+        return;                          \
+    }
+    APTAI_EPI_CASE(0)                                                                             // dgrads
+    APTAI_EPI_CASE(APTAI_EPI_BIAS)
+    APTAI_EPI_CASE(APTAI_EPI_BIAS | EPX_CS)                                                       // q|k|v projection
+    APTAI_EPI_CASE(APTAI_EPI_RESIDUAL)                                                            // dgrads joining the residual gradient
+    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_RESIDUAL)                                           // out-proj / FFN2, evaluation
+    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_RESIDUAL | APTAI_EPI_DROPOUT)                       // out-proj / FFN2, training
+    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_DROPOUT)                                            // feature projection
+    APTAI_EPI_CASE(APTAI_EPI_GELU)                                                                // frozen conv stack
+    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_GELU)                                               // FFN1, evaluation
+    APTAI_EPI_CASE(APTAI_EPI_GELU | EPX_PRE)                                                      // trainable conv stack
+    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_GELU | EPX_PRE)
+    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_GELU | APTAI_EPI_DROPOUT | APTAI_EPI_PRE_DGELU | EPX_PRE)   // FFN1, training
+    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_GELU | APTAI_EPI_PRE_DGELU | EPX_PRE)               // FFN1, training, activation dropout 0
+    APTAI_EPI_CASE(APTAI_EPI_MUL_AUX)                                                             // FFN2 dgrad
+    APTAI_EPI_CASE(APTAI_EPI_DGELU)
+#undef APTAI_EPI_CASE
+    f(EpiWord<-1>{});
+}
+
+template <int FM>
+__device__ __forceinline__ void epilogue_chunk(float (&v)[8], const GemmArgs& g, const int flags_rt, const long m, const int n,
                                                const u32x4 auxq, const u32x4 resq, const uint32_t sd0, const uint32_t sd1) {
+    const int flags = FM >= 0 ? FM : flags_rt;                 // flags_rt = epi_flag_word(g)
     const bool pre_dgelu = (flags & APTAI_EPI_PRE_DGELU) != 0;
-    if (n < g.colscale_n) {                                    // 8-column chunks: colscale_n % 8 == 0 (checked on the host)
+    const bool has_pre = (flags & EPX_PRE) != 0;
+    if ((flags & EPX_CS) && n < g.colscale_n) {                // 8-column chunks: colscale_n % 8 == 0 (checked on the host)
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] *= g.colscale;
     }
     float d[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) d[r] = 1.0f;
-    if (g.out_pre && !pre_dgelu)
+    if (has_pre && !pre_dgelu)
         *(u32x4*)(g.out_pre + m * g.ldc + n) =
             (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
     if (flags & APTAI_EPI_GELU) {
@@ -117,7 +158,7 @@ __device__ __forceinline__ void epilogue_chunk(float (&v)[8], const GemmArgs& g,
             d[r + 1] *= k1;
         }
     }
-    if (g.out_pre && pre_dgelu)
+    if (has_pre && pre_dgelu)
         *(u32x4*)(g.out_pre + m * g.ldc + n) =
             (u32x4){pack2bf(d[0], d[1]), pack2bf(d[2], d[3]), pack2bf(d[4], d[5]), pack2bf(d[6], d[7])};
     if (flags & APTAI_EPI_DGELU) {
@@ -135,6 +176,9 @@ __device__ __forceinline__ void epilogue_chunk(float (&v)[8], const GemmArgs& g,
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[2 * r] += lo_bf(resq[r]); v[2 * r + 1] += hi_bf(resq[r]); }
     }
+#ifdef APTAI_EXP_NOSTORE
+    if (g.M < 0)
+#endif
     *(u32x4*)((bf16_t*)g.C + m * g.ldc + n) =
         (u32x4){pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
 }
@@ -529,73 +573,83 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     //          LDS staging instead of serialising pass after pass.
     // Phase 1: accumulators -> fp32 LDS tile [128][128] (row pitch 528 B: conflict-free 16-B writes of 16 rows).
     // acc[i][j][r]: m = wm*64 + i*16 + (lane&15);  n = wn*64 + j*16 + (lane>>4)*4 + r
-    const int flags = g.flags;
-    const int cl = (tid & 15) * 8;                     // column inside the tile, fixed per thread
-    const int n = n0 + cl;
-    const bool n_ok = n < g.N;
-    u32x4 resv[NPASS], auxv[NPASS];
-    if (!OUT_F32) {
-#pragma unroll
+    // The body is compiled per flag word (epi_dispatch; block-uniform branch); thread / tile indices enter through opaque copies so
+    // that the addresses of all those bodies are not hoisted above the main loop as loop invariants.
+    int tid_e = tid, lane_e = lane, m0_e = __builtin_amdgcn_readfirstlane(m0), n0_e = __builtin_amdgcn_readfirstlane(n0);
+    asm volatile("" : "+v"(tid_e), "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));
+    const int fx = epi_flag_word(g);
+    auto body = [&](auto w) {
+        constexpr int FM = decltype(w)::value;
+        const int flags = FM >= 0 ? FM : fx;
+        const int cl = (tid_e & 15) * 8;                     // column inside the tile, fixed per thread
+        const int n = n0_e + cl;
+        const bool n_ok = n < g.N;
+        u32x4 resv[NPASS], auxv[NPASS];
+        if (!OUT_F32) {
+    #pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int m = m0_e + pass * 16 + (tid_e >> 4);
+                const bool ok = n_ok && m < g.M;
+                resv[pass] = (u32x4){0u, 0u, 0u, 0u};
+                auxv[pass] = (u32x4){0u, 0u, 0u, 0u};
+                if (ok && (flags & APTAI_EPI_RESIDUAL)) resv[pass] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+                if (ok && (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX))) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+            }
+        }
+        __syncthreads();                                   // every wave is done reading the staging buffers
+        {
+            char* ct = smem;
+    #pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int ml = wm * WM + i * 16 + (lane_e & 15);
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int nl = wn * 64 + j * 16 + (lane_e >> 4) * 4;
+                    *(f32x4*)(ct + ml * EPI_PITCH + nl * 4) = acc[i][j];
+                }
+            }
+        }
+        __syncthreads();
+        // Phase 2: thread -> 8 consecutive columns of one row per pass (16 threads cover a 512-B row): every global
+        // access of the epilogue (residual, aux, out_pre, C) is a coalesced 16/32-byte-per-lane row segment.
+        float bias8[8];
+    #pragma unroll
+        for (int r = 0; r < 8; ++r) bias8[r] = 0.f;
+        if ((flags & APTAI_EPI_BIAS) && n_ok) {
+            const f32x4 b0 = *(const f32x4*)(g.bias + n), b1 = *(const f32x4*)(g.bias + n + 4);
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) { bias8[r] = b0[r]; bias8[4 + r] = b1[r]; }
+        }
+        const float alpha = (flags & APTAI_EPI_ALPHA) ? g.alpha : 1.0f;
+        uint32_t sd0 = g.seed0, sd1 = g.seed1;
+        if (flags & APTAI_EPI_DROPOUT) apply_salt(g.salt, sd0, sd1);
+    #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
-            const int m = m0 + pass * 16 + (tid >> 4);
-            const bool ok = n_ok && m < g.M;
-            resv[pass] = (u32x4){0u, 0u, 0u, 0u};
-            auxv[pass] = (u32x4){0u, 0u, 0u, 0u};
-            if (ok && (flags & APTAI_EPI_RESIDUAL)) resv[pass] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
-            if (ok && (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX))) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
-        }
-    }
-    __syncthreads();                                   // every wave is done reading the staging buffers
-    {
-        char* ct = smem;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int ml = wm * WM + i * 16 + (lane & 15);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
-                *(f32x4*)(ct + ml * EPI_PITCH + nl * 4) = acc[i][j];
+            const int ml = pass * 16 + (tid_e >> 4);
+            const int m = m0_e + ml;
+            if (m >= g.M || !n_ok) continue;
+            const f32x4 v0 = *(const f32x4*)(smem + ml * EPI_PITCH + cl * 4);
+            const f32x4 v1 = *(const f32x4*)(smem + ml * EPI_PITCH + cl * 4 + 16);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    #pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = (flags & (APTAI_EPI_BIAS | APTAI_EPI_ALPHA)) ? fmaf(v[r], alpha, bias8[r]) : v[r];
+            if (OUT_F32) {
+                if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder): += res32[m][n..n+7]
+                    const float* R = (const float*)g.residual + (long)m * g.ldr + n;
+                    const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+                }
+                float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
+                *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                continue;
             }
+            epilogue_chunk<FM>(v, g, flags, (long)m, n, auxv[pass], resv[pass], sd0, sd1);
         }
-    }
-    __syncthreads();
-    // Phase 2: thread -> 8 consecutive columns of one row per pass (16 threads cover a 512-B row): every global
-    // access of the epilogue (residual, aux, out_pre, C) is a coalesced 16/32-byte-per-lane row segment.
-    float bias8[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) bias8[r] = 0.f;
-    if ((flags & APTAI_EPI_BIAS) && n_ok) {
-        const f32x4 b0 = *(const f32x4*)(g.bias + n), b1 = *(const f32x4*)(g.bias + n + 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { bias8[r] = b0[r]; bias8[4 + r] = b1[r]; }
-    }
-    const float alpha = (flags & APTAI_EPI_ALPHA) ? g.alpha : 1.0f;
-    uint32_t sd0 = g.seed0, sd1 = g.seed1;
-    if (flags & APTAI_EPI_DROPOUT) apply_salt(g.salt, sd0, sd1);
-#pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int ml = pass * 16 + (tid >> 4);
-        const int m = m0 + ml;
-        if (m >= g.M || !n_ok) continue;
-        const f32x4 v0 = *(const f32x4*)(smem + ml * EPI_PITCH + cl * 4);
-        const f32x4 v1 = *(const f32x4*)(smem + ml * EPI_PITCH + cl * 4 + 16);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = fmaf(v[r], alpha, bias8[r]);
-        if (OUT_F32) {
-            if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder): += res32[m][n..n+7]
-                const float* R = (const float*)g.residual + (long)m * g.ldr + n;
-                const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
-            }
-            float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
-            *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
-            *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-            continue;
-        }
-        epilogue_chunk(v, g, flags, (long)m, n, auxv[pass], resv[pass], sd0, sd1);
-    }
+    };
+    if (OUT_F32) body(EpiWord<-1>{});
+    else epi_dispatch(fx, body);
 }
 
 template <bool A_KM, bool B_KM, bool OUT_F32>
@@ -685,13 +739,26 @@ int launch_gemm(const GemmArgs& g, int nbatch, int nsplit, hipStream_t stream) {
 //    while one wave of the SIMD issues its MFMA cluster the other issues ds_reads + LDS-DMA.
 //  Hazards: RAW - the wait that retires half-tile h sits in the phase BEFORE its first read, in front of a barrier
 //  every wave crosses; WAR - a region is restaged >= 2 phases after its last read (covers the group stagger).
+#ifdef APTAI_STAMPS
+// development only (tools/ab builds, -DAPTAI_STAMPS): per-block time stamps of the 256 x 256 kernel, read back by tools/gemm256_stamps.py
+__device__ unsigned long long g_stamps[4096 * 8];
+#define APTAI_STAMP(slot)                                                                          \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0 && blockIdx.z == 0)           \
+            g_stamps[blockIdx.x * 8 + (slot)] = wall_clock64();                                    \
+    } while (0)
+extern "C" int aptai_debug_read_stamps(void* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
+}
+#else
+#define APTAI_STAMP(slot) do {} while (0)
+#endif
 constexpr int T2_THREADS = 512;
 constexpr int T2_BM = 256, T2_BN = 256;
 constexpr int T2_HALF_BYTES = 128 * BK * 2;             // 16 KiB
 constexpr int T2_BUF_BYTES = 4 * T2_HALF_BYTES;         // A0 A1 B0 B1
 constexpr int T2_SMEM = 2 * T2_BUF_BYTES;               // 128 KiB
-constexpr int T2_EPI_PITCH = T2_BN * 4 + 16;            // fp32 row of 256 columns + pad
-static_assert(64 * T2_EPI_PITCH <= T2_SMEM, "epilogue pass must fit the staging LDS");
+static_assert(128 * T2_BN * 4 <= T2_SMEM, "an epilogue pass (128 fp32 rows, unpadded) must fit the staging LDS");
 
 template <bool KM>
 __device__ __forceinline__ void stage_half(const bf16_t* __restrict__ base, long ld, int row0, int rows_total, int k0,
@@ -751,6 +818,7 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmArgs& g, char* smem, 
     if (total_h >= 6) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    APTAI_STAMP(1);
     // stream-K: the slab stores of the PREVIOUS segment are older than this prologue's loads, vector-memory operations retire in
     // order, so every wave that passed the counted wait above has drained its write-through stores, and every wave has passed
     // it once the barrier releases: the ready flag goes out here, its drain hidden under this prologue's own latency
@@ -828,13 +896,27 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmArgs& g, char* smem, 
     __syncthreads();
 }
 
-// ---- epilogue of one 256 x 256 tile: 4 passes of 64 rows x 256 cols through the (free) staging LDS; ends behind a barrier
-template <bool OUT_F32>
-__device__ __forceinline__ void gemm256_epilogue(const GemmArgs& g, char* smem, const int m0, const int n0, const int split,
-                                                 const f32x4 (&acc)[2][2][4][2], const int tid, const int lane, const int wr,
-                                                 const int wc) {
-    const int flags = g.flags;
-    const int cl = (tid & 31) * 8;
+// ---- epilogue of one 256 x 256 tile; ends behind a barrier.
+// Two passes of 128 rows x 256 cols of fp32 through the (free) staging LDS.  In-kernel stamps (tools/gemm256_stamps.py) put the first
+// form of this epilogue - four 64-row passes written by half of the waves, a rolled loop of [2 LDS reads -> arithmetic -> store] per row
+// with the residual / aux loads inside it - at 7.5 us of a 27 us tile at K = 768 (13-14 us with a GELU): a chain of latencies, not a
+// bandwidth.  Now: every wave stages its half in each pass (4 barriers instead of 8); rows are read back in groups of four with all
+// eight LDS reads and the residual / aux row loads of the group issued before the arithmetic of the first; the staging rows carry no
+// padding (exactly 128 KiB) and are conflict-free both ways - 16-byte chunk c of row r sits at slot (pi(c) ^ (r & 15)) with
+// pi(c) = (c & 32) | ((c & 1) << 4) | ((c >> 1) & 15): the 16 lanes of a write (same chunk, 16 rows) and the 16 lanes of a read (one row,
+// chunks 2L, then 2L + 1) both cover 16 distinct slots of one 256-byte group.
+__device__ __forceinline__ int epi256_off(int row, int c) {
+    const int p = (c & 32) | ((c & 1) << 4) | ((c >> 1) & 15);
+    return row * (T2_BN * 4) + ((p ^ (row & 15)) << 4);
+}
+
+template <bool OUT_F32, int FM>
+__device__ __forceinline__ void gemm256_epilogue_body(const GemmArgs& g, char* smem, const int m0, const int n0, const int split,
+                                                      const f32x4 (&acc)[2][2][4][2], const int tid, const int lane, const int wr,
+                                                      const int wc, const int flags_rt) {
+    const int flags = FM >= 0 ? FM : flags_rt;
+    const int L = tid & 31;
+    const int cl = L * 8;
     const int n = n0 + cl;
     const bool n_ok = n < g.N;
     float bias8[8];
@@ -846,52 +928,89 @@ __device__ __forceinline__ void gemm256_epilogue(const GemmArgs& g, char* smem, 
         for (int r = 0; r < 4; ++r) { bias8[r] = bb0[r]; bias8[4 + r] = bb1[r]; }
     }
     const float alpha = (flags & APTAI_EPI_ALPHA) ? g.alpha : 1.0f;
+    uint32_t sd0 = g.seed0, sd1 = g.seed1;
+    if (!OUT_F32 && (flags & APTAI_EPI_DROPOUT)) apply_salt(g.salt, sd0, sd1);
+    const bool want_res = !OUT_F32 && (flags & APTAI_EPI_RESIDUAL), want_aux = !OUT_F32 && (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX));
+    const int row_in_group = tid >> 5;                  // 16 rows per step, 4 steps per group, 2 groups per pass
+    // residual / aux rows of one group of four steps (16 B per row and thread), issued a group ahead of their use
+    u32x4 resv[2][4], auxv[2][4];
+    auto prefetch = [&](int slot, int pqm, int grp) {
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int pqm = pass >> 1, pwr = pass & 1;      // rows m0 + pqm*128 + pwr*64 + [0,64)
-        if (wr == pwr) {
-#pragma unroll
-            for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int ml = i * 16 + (lane & 15);
-                        const int nl = qn * 128 + wc * 32 + j * 16 + (lane >> 4) * 4;
-                        *(f32x4*)(smem + ml * T2_EPI_PITCH + nl * 4) = acc[pqm][qn][i][j];
-                    }
+        for (int k = 0; k < 4; ++k) {
+            const int m = m0 + pqm * 128 + (grp * 4 + k) * 16 + row_in_group;
+            const bool ok = n_ok && m < g.M;
+            resv[slot][k] = (u32x4){0u, 0u, 0u, 0u};
+            auxv[slot][k] = (u32x4){0u, 0u, 0u, 0u};
+            if (ok && want_res) resv[slot][k] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+            if (ok && want_aux) auxv[slot][k] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
         }
+    };
+    if (want_res || want_aux) prefetch(0, 0, 0);
+#pragma unroll
+    for (int pqm = 0; pqm < 2; ++pqm) {
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *(f32x4*)(smem + epi256_off(wr * 64 + i * 16 + (lane & 15), qn * 32 + wc * 8 + j * 4 + (lane >> 4))) = acc[pqm][qn][i][j];
         __syncthreads();
-#pragma unroll 2
-        for (int it = 0; it < 4; ++it) {
-            const int ml = it * 16 + (tid >> 5);
-            const int m = m0 + pqm * 128 + pwr * 64 + ml;
-            if (m >= g.M || !n_ok) continue;
-            const f32x4 v0 = *(const f32x4*)(smem + ml * T2_EPI_PITCH + cl * 4);
-            const f32x4 v1 = *(const f32x4*)(smem + ml * T2_EPI_PITCH + cl * 4 + 16);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = fmaf(v[r], alpha, bias8[r]);
-            if (OUT_F32) {
-                if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder)
-                    const float* R = (const float*)g.residual + (long)m * g.ldr + n;
-                    const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
+        for (int grp = 0; grp < 2; ++grp) {
+            const int cur = (pqm * 2 + grp) & 1;
+            if ((want_res || want_aux) && (pqm * 2 + grp) < 3) prefetch(cur ^ 1, grp ? pqm + 1 : pqm, grp ^ 1);
+            f32x4 v0[4], v1[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
-                }
-                float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
-                *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
-                *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                continue;
+            for (int k = 0; k < 4; ++k) {
+                const int lr = (grp * 4 + k) * 16 + row_in_group;
+                v0[k] = *(const f32x4*)(smem + epi256_off(lr, 2 * L));
+                v1[k] = *(const f32x4*)(smem + epi256_off(lr, 2 * L + 1));
             }
-            u32x4 auxq = {0u, 0u, 0u, 0u}, resq = {0u, 0u, 0u, 0u};
-            if (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) auxq = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
-            if (flags & APTAI_EPI_RESIDUAL) resq = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
-            uint32_t sd0 = g.seed0, sd1 = g.seed1;
-            if (flags & APTAI_EPI_DROPOUT) apply_salt(g.salt, sd0, sd1);
-            epilogue_chunk(v, g, flags, (long)m, n, auxq, resq, sd0, sd1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = m0 + pqm * 128 + (grp * 4 + k) * 16 + row_in_group;
+                if (m >= g.M || !n_ok) continue;
+                float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
+                if (flags & (APTAI_EPI_BIAS | APTAI_EPI_ALPHA)) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = fmaf(v[r], alpha, bias8[r]);
+                }
+                if (OUT_F32) {
+                    if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder)
+                        const float* R = (const float*)g.residual + (long)m * g.ldr + n;
+                        const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+                    }
+                    float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
+                    *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                    continue;
+                }
+                epilogue_chunk<FM>(v, g, flags, (long)m, n, auxv[cur][k], resv[cur][k], sd0, sd1);
+            }
         }
         __syncthreads();
+    }
+}
+
+template <bool OUT_F32>
+__device__ __forceinline__ void gemm256_epilogue(const GemmArgs& g, char* smem, const int m0, const int n0, const int split,
+                                                 const f32x4 (&acc)[2][2][4][2], const int tid, const int lane, const int wr,
+                                                 const int wc) {
+    // Everything the epilogue derives from the thread / tile indices is recomputed from opaque copies: otherwise the addresses of
+    // all the specialised bodies are hoisted above the main loop as loop invariants and spill INSIDE it (measured: main loop 18.4 ->
+    // 23.4 us per tile at K = 768).
+    int tid_e = tid, lane_e = lane, m0_e = __builtin_amdgcn_readfirstlane(m0), n0_e = __builtin_amdgcn_readfirstlane(n0);
+    asm volatile("" : "+v"(tid_e), "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));
+    const int fx = epi_flag_word(g);
+    if (OUT_F32) {                                      // fp32 outputs (weight gradients, exact mode): alpha / bias / fp32 residual only
+        gemm256_epilogue_body<true, -1>(g, smem, m0_e, n0_e, split, acc, tid_e, lane_e, wr, wc, fx);
+    } else {
+        epi_dispatch(fx, [&](auto w) {
+            gemm256_epilogue_body<false, decltype(w)::value>(g, smem, m0_e, n0_e, split, acc, tid_e, lane_e, wr, wc, fx);
+        });
     }
 }
 
@@ -926,8 +1045,22 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
     int kt_end = kt_begin + g.ktiles_per_split;
     kt_end = kt_end < total_kt ? kt_end : total_kt;
     f32x4 acc[2][2][4][2];                              // [qm][qn][i][j]
+    APTAI_STAMP(0);
     gemm256_mainloop<A_KM, B_KM>(g, smem, m0, n0, kt_begin, kt_end - kt_begin, acc, tid, lane, wr, wc, wave_base_tid);
+    APTAI_STAMP(2);
     gemm256_epilogue<OUT_F32>(g, smem, m0, n0, split, acc, tid, lane, wr, wc);
+    APTAI_STAMP(3);
+#ifdef APTAI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    APTAI_STAMP(4);
+    if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_stamps[blockIdx.x * 8 + 5] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
 
 // =====================================================================================================================
@@ -1388,68 +1521,77 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
 
     // ------------------------------------------------------------------ epilogue (same scheme as gemm_kernel)
     // 128 x 192 outputs = 3072 chunks of 8 columns = 6 passes x 512 threads; chunk c -> row c / 24, column 8 * (c % 24)
-    const int flags = g.flags;
-    u32x4 resv[6], auxv[6];
-#pragma unroll
-    for (int pass = 0; pass < 6; ++pass) {
-        resv[pass] = (u32x4){0u, 0u, 0u, 0u};
-        auxv[pass] = (u32x4){0u, 0u, 0u, 0u};
-    }
-    if (!OUT_F32 && (flags & (APTAI_EPI_RESIDUAL | APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX))) {     // uniform; addresses clamped, no per-lane branches
-#pragma unroll
+    // compiled per flag word, indices through opaque copies (see gemm_tile_body)
+    int tid_e = tid, lane_e = lane, m0_e = __builtin_amdgcn_readfirstlane(m0), n0_e = __builtin_amdgcn_readfirstlane(n0);
+    asm volatile("" : "+v"(tid_e), "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));
+    const int fx = epi_flag_word(g);
+    auto body = [&](auto w) {
+        constexpr int FM = decltype(w)::value;
+        const int flags = FM >= 0 ? FM : fx;
+        u32x4 resv[6], auxv[6];
+    #pragma unroll
         for (int pass = 0; pass < 6; ++pass) {
-            const int c = pass * T3_THREADS + tid, ml = c / 24, cl = (c - ml * 24) * 8;
-            int m = m0 + ml, n = n0 + cl;
-            m = m < g.M ? m : g.M - 1;
-            n = n <= g.N - 8 ? n : g.N - 8;
-            if (flags & APTAI_EPI_RESIDUAL) resv[pass] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
-            if (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+            resv[pass] = (u32x4){0u, 0u, 0u, 0u};
+            auxv[pass] = (u32x4){0u, 0u, 0u, 0u};
         }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ml = wm * 64 + i * 16 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int nl = wn * 48 + j * 16 + (lane >> 4) * 4;
-            *(f32x4*)(smem + ml * T3_EPI_PITCH + nl * 4) = acc[i][j];
-        }
-    }
-    __syncthreads();
-    const float alpha = (flags & APTAI_EPI_ALPHA) ? g.alpha : 1.0f;
-    uint32_t sd0 = g.seed0, sd1 = g.seed1;
-    if (flags & APTAI_EPI_DROPOUT) apply_salt(g.salt, sd0, sd1);
-#pragma unroll
-    for (int pass = 0; pass < 6; ++pass) {
-        const int c = pass * T3_THREADS + tid, ml = c / 24, cl = (c - ml * 24) * 8;
-        const int m = m0 + ml, n = n0 + cl;
-        if (m >= g.M || n >= g.N) continue;
-        const f32x4 v0 = *(const f32x4*)(smem + ml * T3_EPI_PITCH + cl * 4);
-        const f32x4 v1 = *(const f32x4*)(smem + ml * T3_EPI_PITCH + cl * 4 + 16);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (flags & APTAI_EPI_BIAS) {
-            const f32x4 b0 = *(const f32x4*)(g.bias + n), b1 = *(const f32x4*)(g.bias + n + 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = fmaf(v[r], alpha, b0[r]); v[4 + r] = fmaf(v[4 + r], alpha, b1[r]); }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] *= alpha;
-        }
-        if (OUT_F32) {
-            if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder): += res32[m][n..n+7]
-                const float* R = (const float*)g.residual + (long)m * g.ldr + n;
-                const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+        if (!OUT_F32 && (flags & (APTAI_EPI_RESIDUAL | APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX))) {     // uniform; addresses clamped, no per-lane_e branches
+    #pragma unroll
+            for (int pass = 0; pass < 6; ++pass) {
+                const int c = pass * T3_THREADS + tid_e, ml = c / 24, cl = (c - ml * 24) * 8;
+                int m = m0_e + ml, n = n0_e + cl;
+                m = m < g.M ? m : g.M - 1;
+                n = n <= g.N - 8 ? n : g.N - 8;
+                if (flags & APTAI_EPI_RESIDUAL) resv[pass] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+                if (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
             }
-            float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
-            *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
-            *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-            continue;
         }
-        epilogue_chunk(v, g, flags, (long)m, n, auxv[pass], resv[pass], sd0, sd1);
-        __builtin_amdgcn_sched_barrier(0);             // keep the passes apart: interleaving all six spills
-    }
+    #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = wm * 64 + i * 16 + (lane_e & 15);
+    #pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int nl = wn * 48 + j * 16 + (lane_e >> 4) * 4;
+                *(f32x4*)(smem + ml * T3_EPI_PITCH + nl * 4) = acc[i][j];
+            }
+        }
+        __syncthreads();
+        const float alpha = (flags & APTAI_EPI_ALPHA) ? g.alpha : 1.0f;
+        uint32_t sd0 = g.seed0, sd1 = g.seed1;
+        if (flags & APTAI_EPI_DROPOUT) apply_salt(g.salt, sd0, sd1);
+    #pragma unroll
+        for (int pass = 0; pass < 6; ++pass) {
+            const int c = pass * T3_THREADS + tid_e, ml = c / 24, cl = (c - ml * 24) * 8;
+            const int m = m0_e + ml, n = n0_e + cl;
+            if (m >= g.M || n >= g.N) continue;
+            const f32x4 v0 = *(const f32x4*)(smem + ml * T3_EPI_PITCH + cl * 4);
+            const f32x4 v1 = *(const f32x4*)(smem + ml * T3_EPI_PITCH + cl * 4 + 16);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (flags & APTAI_EPI_BIAS) {
+                const f32x4 b0 = *(const f32x4*)(g.bias + n), b1 = *(const f32x4*)(g.bias + n + 4);
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = fmaf(v[r], alpha, b0[r]); v[4 + r] = fmaf(v[4 + r], alpha, b1[r]); }
+            } else if (flags & APTAI_EPI_ALPHA) {
+    #pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] *= alpha;
+            }
+            if (OUT_F32) {
+                if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder): += res32[m][n..n+7]
+                    const float* R = (const float*)g.residual + (long)m * g.ldr + n;
+                    const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+                }
+                float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
+                *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
+                *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                continue;
+            }
+            epilogue_chunk<FM>(v, g, flags, (long)m, n, auxv[pass], resv[pass], sd0, sd1);
+            __builtin_amdgcn_sched_barrier(0);             // keep the passes apart: interleaving all six spills
+        }
+    };
+    if (OUT_F32) body(EpiWord<-1>{});
+    else epi_dispatch(fx, body);
 }
 
 template <bool A_KM, bool B_KM, bool OUT_F32>

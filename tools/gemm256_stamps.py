@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Development: where a 256 x 256 tile's time goes.  Needs a build with -DAPTAI_STAMPS (tools/ab/lib_stamps.so, APTAI_HIP_LIB):
+per-block wall-clock stamps (100 MHz) at entry / first operands landed / main loop done / epilogue issued / stores acknowledged."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from aptai_amd import _lib, ops
+
+
+def run(M, N, K, lda=None, gelu=False):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rows = M + 16 if lda is None else (M * lda) // 512 + 64
+    a = (torch.randn(rows, 512 if lda else K, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.03).to(torch.bfloat16)
+    out = torch.empty(M + 8, N, device="cuda", dtype=torch.bfloat16)
+    kw = dict(lda=lda) if lda else {}
+    for _ in range(3):
+        ops.gemm(a, w, M, N, K, out=out, ldc=N, gelu=gelu, tile=256, **kw)
+    torch.cuda.synchronize()
+    buf = np.zeros(4096 * 8, dtype=np.uint64)
+    lib = _lib.lib()
+    lib.aptai_debug_read_stamps.argtypes = [ctypes.c_void_p]
+    lib.aptai_debug_read_stamps.restype = ctypes.c_int
+    assert lib.aptai_debug_read_stamps(buf.ctypes.data) == 0
+    nb = min(4096, ((M + 255) // 256) * ((N + 255) // 256))
+    st = buf.reshape(4096, 8)[:nb].astype(np.int64)
+    t0 = st[:, 0].min()
+    rel = (st[:, :5] - t0) / 100.0                      # us
+    d = np.diff(rel, axis=1)
+    print(f"== {M} x {N} x {K} lda={lda} gelu={gelu}: {nb} blocks, kernel span {rel[:, 4].max():.1f} us")
+    names = ["entry->operands", "main loop", "epilogue", "store ack"]
+    for i, n in enumerate(names):
+        print(f"   {n:16s} mean {d[:, i].mean():6.2f}  p10 {np.percentile(d[:, i], 10):6.2f}  p90 {np.percentile(d[:, i], 90):6.2f} us")
+    print(f"   block total      mean {(rel[:, 4] - rel[:, 0]).mean():6.2f} us")
+    # per CU: gap between a block's end and the next block's entry on the same CU
+    hw = st[:, 5]
+    key = ((hw >> 32) & 0xf) * 4096 + ((hw & 0xffffffff) >> 8 & 0xf) + (((hw & 0xffffffff) >> 13) & 0x7) * 16 + (((hw & 0xffffffff) >> 16) & 0x1) * 128
+    gaps = []
+    for k in np.unique(key):
+        idx = np.where(key == k)[0]
+        idx = idx[np.argsort(rel[idx, 0])]
+        for a_, b_ in zip(idx[:-1], idx[1:]):
+            gaps.append(rel[b_, 0] - rel[a_, 4])
+    if gaps:
+        gaps = np.array(gaps)
+        print(f"   slots seen {len(np.unique(key))}; end->next entry on the same slot: mean {gaps.mean():6.2f}  p10 {np.percentile(gaps, 10):6.2f}  p90 {np.percentile(gaps, 90):6.2f} us")
+    print(f"   entry times: first {np.sort(rel[:, 0])[:3]}, block 255 {np.sort(rel[:, 0])[min(255, nb - 1)]:.2f}")
+
+
+if __name__ == "__main__":
+    run(8192, 2048, 768)
+    run(8192, 2048, 3072)
+    run(255984, 512, 1536, lda=1024)
+    run(255984, 512, 1536, lda=1024, gelu=True)
