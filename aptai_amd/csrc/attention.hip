@@ -19,6 +19,20 @@
 
 namespace {
 
+#ifdef APTAI_STAMPS
+// development only (tools/ab builds): per-block wall-clock stamps (100 MHz), see tools/attn_stamps.py
+__device__ unsigned long long g_attn_stamps[3 * 1024 * 8];
+#define ATTN_STAMP(k, slot)                                                                                       \
+    do {                                                                                                          \
+        if (threadIdx.x == 0) {                                                                                   \
+            const int bl = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                        \
+            if (bl < 1024) g_attn_stamps[((k) * 1024 + bl) * 8 + (slot)] = wall_clock64();                         \
+        }                                                                                                         \
+    } while (0)
+#else
+#define ATTN_STAMP(k, slot) do {} while (0)
+#endif
+
 constexpr int HD = 64;          // head dim
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -93,6 +107,7 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // fragment loads / accumulator stores touch 32-64 cache lines per instruction)
 constexpr int OUT_PITCH = 144;                                  // bytes per staged row (128 + 16: odd number of 16-B units)
 constexpr int STAGE_BYTES = 4 * 32 * OUT_PITCH;                 // 18 432 B: 32 rows per wave
+constexpr int DQ_STAGE = 2 * 128 * 128;                           // dQ kernel: Q and dO tiles side by side (>= STAGE_BYTES)
 constexpr int DKDV_BLOCKS = 3;                                  // dK/dV kernel, pre-scaled Q (the model's path): blocks per CU (register budget 168)
 constexpr int DKDV_KV_BYTES = 2 * 128 * 128;                    // its resident K and V tiles
 
@@ -174,6 +189,7 @@ template <bool V> struct Flag { static constexpr bool value = V; };
 template <bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[FWD_SMEM];
+    ATTN_STAMP(0, 0);
     if (DROP) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     int tile_x, hd, b;
@@ -229,6 +245,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         }
     }
     __syncthreads();
+    ATTN_STAMP(0, 1);
 
     // one key tile; FIRST: take the reference from this tile's maximum; MASK: keys >= len are excluded (last tile only)
     auto tile = [&](auto first_flag, auto mask_flag, const int t) {
@@ -328,6 +345,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         for (int t = 1; t + 1 < ntiles; ++t) tile(Flag<false>{}, Flag<false>{}, t);
         tile(Flag<false>{}, Flag<true>{}, ntiles - 1);
     }
+    ATTN_STAMP(0, 2);
     const float l_tot = l_run;                 // both half-waves' keys are in (psum was exchanged per tile)
     const float inv = __frcp_rn(l_tot) * a.dscale;
     if (a.lse2 && h == 0) a.lse2[((long)b * a.heads + hd) * a.Tp + q] = ref + fast_log2(l_tot);
@@ -367,6 +385,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
             }
         }
     }
+    ATTN_STAMP(0, 3);
+#ifdef APTAI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_STAMP(0, 4);
+#endif
 }
 
 // ================================================================================== backward: dK, dV
@@ -385,6 +408,7 @@ __global__ __launch_bounds__(256, PRE ? DKDV_BLOCKS : 2) void attn_bwd_dkdv_kern
     float* sL = (float*)(smem + STAGE_BYTES);           // [0,32) lse2, [32,64) delta, [64,96) dropout row hash of the tile's queries
     char* sKall = smem + STAGE_BYTES + 384;
     char* sVall = sKall + 128 * 128;
+    ATTN_STAMP(1, 0);
     if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     int tile_x, hd, b;
@@ -439,6 +463,7 @@ __global__ __launch_bounds__(256, PRE ? DKDV_BLOCKS : 2) void attn_bwd_dkdv_kern
     const uint32_t rowid0 = (uint32_t)((b * a.heads + hd) * a.Tp) + (uint32_t)(tid & 31);
     uint32_t hreg = 0;
     if (a.thr16 && tid >= 32 && tid < 64) hreg = rng_hash(rowid0, a.seed0, a.seed1);
+    ATTN_STAMP(1, 1);
     for (int t = 0; t < nq; ++t) {
         __syncthreads();
         *(u32x4*)(sQ + soff) = qreg;
@@ -529,20 +554,27 @@ __global__ __launch_bounds__(256, PRE ? DKDV_BLOCKS : 2) void attn_bwd_dkdv_kern
         }
     }
     __syncthreads();                                           // the Q / dO tiles become the epilogue staging area
+    ATTN_STAMP(1, 2);
     char* sw = smem + wave * (32 * OUT_PITCH);
     // dK = scale * dS^T Q; with PRE the staged rows are Q' = scale * log2(e) * Q, so the factor left over is ln 2
     store_rows_bf16(sw, dKT, (PRE ? 0.6931471805599453f : a.scale) * a.dscale, dK0 + (long)(wave * 32) * a.ld, a.ld, lane);
     store_rows_bf16(sw, dVT, a.dscale, dV0 + (long)(wave * 32) * a.ld, a.ld, lane);
+    ATTN_STAMP(1, 3);
+#ifdef APTAI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_STAMP(1, 4);
+#endif
 }
 
 // ================================================================================== backward: dQ
 // grid (Tp/128, heads, B); wave w owns queries q0 = qt*128 + w*32 .. +31; loops over 32-key tiles.
 template <bool PRE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[STAGE_BYTES + 512];   // prologue / epilogue staging; K, V tiles (32 keys)
+    __shared__ __attribute__((aligned(16))) char smem[DQ_STAGE + 512];      // prologue: Q and dO tiles; K, V tiles (32 keys); epilogue staging
     char* sK = smem;
     char* sV = smem + 32 * 128;
-    float* sDel = (float*)(smem + STAGE_BYTES);                             // delta of the block's 128 queries
+    float* sDel = (float*)(smem + DQ_STAGE);                                // delta of the block's 128 queries
+    ATTN_STAMP(2, 0);
     if (a.thr16) apply_salt(a.salt, a.seed0, a.seed1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     int tile_x, hd, b;
@@ -553,46 +585,72 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
     len = len < 1 ? 1 : (len > a.Tp ? a.Tp : len);
     const long rowbase = (long)b * a.Tp;
     const LaneOffs lo = lane_offs(lane);
-    // Q and dO fragments through LDS (whole 128-byte rows per 8 lanes), one tensor at a time through the same 16 KB
+    // Prologue.  In-kernel stamps (tools/attn_stamps.py) put its first form - stage Q, barrier, fragments, barrier, stage dO, the delta
+    // loop with its own loads, barrier - at 8.2 us of a 27 us block: three global-memory latencies in series.  Now every global load of
+    // the prologue is issued before the first wait (Q and dO rows, the dO / O values of delta, lse2, the first K / V tile further down),
+    // Q and dO tiles sit side by side in LDS, and one barrier separates the writes from the reads.
     bf16x8 qf[4], df[4];
-    stage_rows128(smem, a.qkv + (rowbase + qb0) * a.ld + hd * HD, a.ld, tid);
-    __syncthreads();
+    const bf16_t* Kb = a.qkv + rowbase * a.ld + a.H + hd * HD;
+    const bf16_t* Vb = Kb + a.H;
+    const int srow = tid >> 3, sch = tid & 7;
+    const int soff = tile_off(srow, sch);
+    const long gk = (long)srow * a.ld + sch * 8;
+    u32x4 kreg = *(const u32x4*)(Kb + gk), vreg = *(const u32x4*)(Vb + gk);
+    const bf16_t* Qrows = a.qkv + (rowbase + qb0) * a.ld + hd * HD;
+    const bf16_t* Drows = a.dctx + (rowbase + qb0) * a.ldo + hd * HD;
+    u32x4 qst[4], dst[4];
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds) qf[ds] = rd_row(smem, lo, wave, ds);
-    __syncthreads();
-    stage_rows128(smem, a.dctx + (rowbase + qb0) * a.ldo + hd * HD, a.ldo, tid);
-    const float lse_q = a.lse2[((long)b * a.heads + hd) * a.Tp + q];
+    for (int it = 0; it < 4; ++it) {
+        const int cid = it * 256 + tid, row = cid >> 3, ch = cid & 7;
+        qst[it] = *(const u32x4*)(Qrows + (long)row * a.ld + ch * 8);
+        dst[it] = *(const u32x4*)(Drows + (long)row * a.ldo + ch * 8);
+    }
     // delta = rowsum(dO * O) of the block's queries, 16 lanes per row (the fp32 context keeps it accurate): every load
     // instruction covers 4 whole rows.  Written once for the dK/dV kernel, which is launched after.
-    {
-        const int part = lane & 15, rsub = lane >> 4;
+    const int part = lane & 15, rsub = lane >> 4;
+    f32x4 ovv[8];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = wave * 32 + it * 4 + rsub;
-            const long g = (rowbase + qb0 + row) * a.ldo + hd * HD + part * 4;
-            const u32x2 dv = *(const u32x2*)(a.dctx + g);
-            float o[4];
-            if (a.o32) {
-                const f32x4 ov = *(const f32x4*)(a.o32 + g);
-                o[0] = ov[0]; o[1] = ov[1]; o[2] = ov[2]; o[3] = ov[3];
-            } else {
-                const u32x2 ov = *(const u32x2*)(a.ctx + g);
-                o[0] = lo_bf(ov[0]); o[1] = hi_bf(ov[0]); o[2] = lo_bf(ov[1]); o[3] = hi_bf(ov[1]);
-            }
-            float acc = lo_bf(dv[0]) * o[0];
-            acc = fmaf(hi_bf(dv[0]), o[1], acc);
-            acc = fmaf(lo_bf(dv[1]), o[2], acc);
-            acc = fmaf(hi_bf(dv[1]), o[3], acc);
-            acc += __shfl_xor(acc, 8, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 1, 64);
-            if (part == 0) sDel[row] = acc;
+    for (int it = 0; it < 8; ++it) {
+        const int row = wave * 32 + it * 4 + rsub;
+        const long g = (rowbase + qb0 + row) * a.ldo + hd * HD + part * 4;
+        if (a.o32) {
+            ovv[it] = *(const f32x4*)(a.o32 + g);
+        } else {
+            const u32x2 ov = *(const u32x2*)(a.ctx + g);
+            ovv[it] = (f32x4){lo_bf(ov[0]), hi_bf(ov[0]), lo_bf(ov[1]), hi_bf(ov[1])};
         }
     }
-    __syncthreads();
+    const float lse_q = a.lse2[((long)b * a.heads + hd) * a.Tp + q];
+    char* sQt = smem;
+    char* sDt = smem + 128 * 128;
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds) df[ds] = rd_row(smem, lo, wave, ds);
+    for (int it = 0; it < 4; ++it) {
+        const int cid = it * 256 + tid, row = cid >> 3, ch = cid & 7;
+        *(u32x4*)(sQt + tile_off(row, ch)) = qst[it];
+        *(u32x4*)(sDt + tile_off(row, ch)) = dst[it];
+    }
+    ATTN_STAMP(2, 5);
+    __syncthreads();
+    ATTN_STAMP(2, 6);
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) { qf[ds] = rd_row(sQt, lo, wave, ds); df[ds] = rd_row(sDt, lo, wave, ds); }
+    // the dO values of delta come from the staged tile (the prologue is an HBM burst of every block at once: 12.6 MB less of it)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = wave * 32 + it * 4 + rsub;
+        const u32x2 dv = *(const u32x2*)(sDt + tile_off(row, part >> 1) + ((part & 1) << 3));
+        float acc = lo_bf(dv[0]) * ovv[it][0];
+        acc = fmaf(hi_bf(dv[0]), ovv[it][1], acc);
+        acc = fmaf(lo_bf(dv[1]), ovv[it][2], acc);
+        acc = fmaf(hi_bf(dv[1]), ovv[it][3], acc);
+        acc += __shfl_xor(acc, 8, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 1, 64);
+        if (part == 0) sDel[row] = acc;
+    }
+    ATTN_STAMP(2, 7);
+    __syncthreads();
     float del_q = sDel[wave * 32 + (lane & 31)];
     __syncthreads();                                           // the staging area becomes the K / V tiles
     // with attention dropout dS = dscale * P (keep * dP - delta / dscale): both backward kernels work with delta / dscale and
@@ -602,16 +660,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
     f32x16 dQT[2];
     dQT[0] = dQT[1] = (f32x16)(0.f);
     const int nk = (len + 31) >> 5;
-    const bf16_t* Kb = a.qkv + rowbase * a.ld + a.H + hd * HD;
-    const bf16_t* Vb = Kb + a.H;
-    const int srow = tid >> 3, sch = tid & 7;
-    const int soff = tile_off(srow, sch);
-    const long gk = (long)srow * a.ld + sch * 8;
-    u32x4 kreg = *(const u32x4*)(Kb + gk), vreg = *(const u32x4*)(Vb + gk);
     uint32_t hbase = 0;                      // dropout: row hash of this lane's query + 2 h K1 (see the forward kernel)
     if (a.thr16) hbase = rng_hash((uint32_t)((b * a.heads + hd) * a.Tp + q), a.seed0, a.seed1) + (uint32_t)(2 * h) * ATTN_K1;
     const float c = a.c;
     const f32x16 cs = (f32x16)(PRE ? -lse_q : 0.f), cd = (f32x16)(PRE ? -del_q : 0.f);
+    ATTN_STAMP(2, 1);
     for (int t = 0; t < nk; ++t) {
         __syncthreads();
         *(u32x4*)(sK + soff) = kreg;
@@ -656,8 +709,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
         }
     }
     __syncthreads();                                           // the K / V tiles become the epilogue staging area
+    ATTN_STAMP(2, 2);
     store_rows_bf16(smem + wave * (32 * OUT_PITCH), dQT, a.scale * a.dscale,
                     a.dqkv + (rowbase + qb0 + wave * 32) * a.ld + hd * HD, a.ld, lane);
+    ATTN_STAMP(2, 3);
+#ifdef APTAI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_STAMP(2, 4);
+#endif
 }
 
 int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens, int64_t B, int64_t Tp, int64_t H,
@@ -681,6 +740,12 @@ int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens
 }
 
 }  // namespace
+
+#ifdef APTAI_STAMPS
+extern "C" int aptai_debug_read_attn_stamps(void* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int aptai_attention_fwd(const void* qkv, const int32_t* lens, void* ctx, float* lse2, float* ctx_f32, int64_t B,
                                    int64_t Tp, int64_t H, int64_t heads, float scale, float dropout_p, uint64_t seed,

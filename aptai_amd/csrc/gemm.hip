@@ -15,6 +15,9 @@
 // (D = colfrag x rowfrag) so each lane ends up with 4 consecutive output columns -> 8/16-byte stores.
 #include <stdlib.h>
 
+#include <mutex>
+#include <set>
+
 #include "common.h"
 
 namespace {
@@ -95,30 +98,47 @@ __device__ __forceinline__ int epi_flag_word(const GemmArgs& g) {
     return g.flags | (g.out_pre ? EPX_PRE : 0) | (g.colscale_n > 0 ? EPX_CS : 0);
 }
 template <int FM> struct EpiWord { static constexpr int value = FM; };
+#define APTAI_EPI_WORDS(X)                                                                                                  \
+    X(0)                                                                  /* dgrads */                                      \
+    X(APTAI_EPI_BIAS)                                                                                                       \
+    X(APTAI_EPI_BIAS | EPX_CS)                                            /* q|k|v projection */                            \
+    X(APTAI_EPI_RESIDUAL)                                                 /* dgrads joining the residual gradient */        \
+    X(APTAI_EPI_BIAS | APTAI_EPI_RESIDUAL)                                /* out-proj / FFN2, evaluation */                 \
+    X(APTAI_EPI_BIAS | APTAI_EPI_RESIDUAL | APTAI_EPI_DROPOUT)            /* out-proj / FFN2, training */                   \
+    X(APTAI_EPI_BIAS | APTAI_EPI_DROPOUT)                                 /* feature projection */                          \
+    X(APTAI_EPI_GELU)                                                     /* frozen conv stack */                           \
+    X(APTAI_EPI_BIAS | APTAI_EPI_GELU)                                    /* FFN1, evaluation */                            \
+    X(APTAI_EPI_GELU | EPX_PRE)                                           /* trainable conv stack */                        \
+    X(APTAI_EPI_BIAS | APTAI_EPI_GELU | EPX_PRE)                                                                            \
+    X(APTAI_EPI_BIAS | APTAI_EPI_GELU | APTAI_EPI_DROPOUT | APTAI_EPI_PRE_DGELU | EPX_PRE)   /* FFN1, training */           \
+    X(APTAI_EPI_BIAS | APTAI_EPI_GELU | APTAI_EPI_PRE_DGELU | EPX_PRE)    /* FFN1, training, activation dropout 0 */        \
+    X(APTAI_EPI_MUL_AUX)                                                  /* FFN2 dgrad */                                  \
+    X(APTAI_EPI_DGELU)
 template <class F>
 __device__ __forceinline__ void epi_dispatch(const int fx, F&& f) {
-#define APTAI_EPI_CASE(W)               \
-    if (fx == (W)) {                     \
-        f(EpiWord<(W)>{});               \
-        return;                          \
+#define APTAI_EPI_CASE(W)  \
+    if (fx == (W)) {        \
+        f(EpiWord<(W)>{});  \
+        return;             \
     }
-    APTAI_EPI_CASE(0)                                                                             // dgrads
-    APTAI_EPI_CASE(APTAI_EPI_BIAS)
-    APTAI_EPI_CASE(APTAI_EPI_BIAS | EPX_CS)                                                       // q|k|v projection
-    APTAI_EPI_CASE(APTAI_EPI_RESIDUAL)                                                            // dgrads joining the residual gradient
-    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_RESIDUAL)                                           // out-proj / FFN2, evaluation
-    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_RESIDUAL | APTAI_EPI_DROPOUT)                       // out-proj / FFN2, training
-    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_DROPOUT)                                            // feature projection
-    APTAI_EPI_CASE(APTAI_EPI_GELU)                                                                // frozen conv stack
-    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_GELU)                                               // FFN1, evaluation
-    APTAI_EPI_CASE(APTAI_EPI_GELU | EPX_PRE)                                                      // trainable conv stack
-    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_GELU | EPX_PRE)
-    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_GELU | APTAI_EPI_DROPOUT | APTAI_EPI_PRE_DGELU | EPX_PRE)   // FFN1, training
-    APTAI_EPI_CASE(APTAI_EPI_BIAS | APTAI_EPI_GELU | APTAI_EPI_PRE_DGELU | EPX_PRE)               // FFN1, training, activation dropout 0
-    APTAI_EPI_CASE(APTAI_EPI_MUL_AUX)                                                             // FFN2 dgrad
-    APTAI_EPI_CASE(APTAI_EPI_DGELU)
+    APTAI_EPI_WORDS(APTAI_EPI_CASE)
 #undef APTAI_EPI_CASE
     f(EpiWord<-1>{});
+}
+// host side, APTAI_EPI_TRACE=1: report each flag word of a bf16-output launch once, and whether it has a compiled body
+void epi_trace(const GemmArgs& g, int tile) {
+    static const bool on = getenv("APTAI_EPI_TRACE") != nullptr;
+    if (!on) return;
+    static std::mutex mu;
+    static std::set<int> seen;
+    const int w = g.flags | (g.out_pre ? EPX_PRE : 0) | (g.colscale_n > 0 ? EPX_CS : 0);
+    std::lock_guard<std::mutex> lk(mu);
+    if (!seen.insert(w).second) return;
+    bool listed = false;
+#define APTAI_EPI_CASE(W) listed = listed || (w == (W));
+    APTAI_EPI_WORDS(APTAI_EPI_CASE)
+#undef APTAI_EPI_CASE
+    fprintf(stderr, "[aptai epi] flag word 0x%x (tile %d, %d x %d x %d): %s\n", w, tile, g.M, g.N, g.K, listed ? "compiled" : "RUN-TIME form");
 }
 
 template <int FM>
@@ -1773,6 +1793,7 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     // 71.5 -> 76.7 us, FFN2 dgrad 63.6 -> 67.1, QKV forward 45.7 -> 48.8): their co-resident tiles then share B panels but
     // spread over 8 A panels, and A is the operand they re-read most
     if (g.raster_gm < 0) g.raster_gm = ((d->a_kmajor && d->b_kmajor) || tile == 192 || tile == 256 || tile == 257) ? 8 : 0;
+    if (!f32) epi_trace(g, tile);
     int rc;
     if (tile == 257) {
         if (!d->a_kmajor && !d->b_kmajor) rc = f32 ? launch_gemm256_sk<false, false, true>(g, d->sk_workspace, stream) : launch_gemm256_sk<false, false, false>(g, d->sk_workspace, stream);
