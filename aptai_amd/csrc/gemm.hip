@@ -69,6 +69,21 @@ struct GemmArgs {
     long sA[2], sB[2], sC[2], sBias[2], sR[2], sAux[2];
 };
 
+#ifdef APTAI_STAMPS
+// development only (tools/ab builds, -DAPTAI_STAMPS): per-block time stamps of the 256 x 256 kernel, read back by tools/gemm256_stamps.py
+__device__ unsigned long long g_stamps[4096 * 8];
+#define APTAI_STAMP(slot)                                                                          \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0 && blockIdx.z == 0)           \
+            g_stamps[blockIdx.x * 8 + (slot)] = wall_clock64();                                    \
+    } while (0)
+extern "C" int aptai_debug_read_stamps(void* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
+}
+#else
+#define APTAI_STAMP(slot) do {} while (0)
+#endif
+
 __device__ __forceinline__ int km_swz(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
 
 // gelu(x) and gelu'(x) together (shared sigmoid): forward epilogues that save the activation derivative for the backward
@@ -314,6 +329,7 @@ __device__ __forceinline__ void raster2d(int bid, int tiles_m, int tiles_n, int 
 template <bool A_KM, bool B_KM, bool OUT_F32, int BM_T = 128>
 __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const int batch, const int split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    APTAI_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -595,6 +611,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     // acc[i][j][r]: m = wm*64 + i*16 + (lane&15);  n = wn*64 + j*16 + (lane>>4)*4 + r
     // The body is compiled per flag word (epi_dispatch; block-uniform branch); thread / tile indices enter through opaque copies so
     // that the addresses of all those bodies are not hoisted above the main loop as loop invariants.
+    APTAI_STAMP(2);
     int tid_e = tid, lane_e = lane, m0_e = __builtin_amdgcn_readfirstlane(m0), n0_e = __builtin_amdgcn_readfirstlane(n0);
     asm volatile("" : "+v"(tid_e), "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));
     const int fx = epi_flag_word(g);
@@ -670,6 +687,11 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
     };
     if (OUT_F32) body(EpiWord<-1>{});
     else epi_dispatch(fx, body);
+    APTAI_STAMP(3);
+#ifdef APTAI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    APTAI_STAMP(4);
+#endif
 }
 
 template <bool A_KM, bool B_KM, bool OUT_F32>
@@ -759,20 +781,6 @@ int launch_gemm(const GemmArgs& g, int nbatch, int nsplit, hipStream_t stream) {
 //    while one wave of the SIMD issues its MFMA cluster the other issues ds_reads + LDS-DMA.
 //  Hazards: RAW - the wait that retires half-tile h sits in the phase BEFORE its first read, in front of a barrier
 //  every wave crosses; WAR - a region is restaged >= 2 phases after its last read (covers the group stagger).
-#ifdef APTAI_STAMPS
-// development only (tools/ab builds, -DAPTAI_STAMPS): per-block time stamps of the 256 x 256 kernel, read back by tools/gemm256_stamps.py
-__device__ unsigned long long g_stamps[4096 * 8];
-#define APTAI_STAMP(slot)                                                                          \
-    do {                                                                                           \
-        if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0 && blockIdx.z == 0)           \
-            g_stamps[blockIdx.x * 8 + (slot)] = wall_clock64();                                    \
-    } while (0)
-extern "C" int aptai_debug_read_stamps(void* host_out) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : 1;
-}
-#else
-#define APTAI_STAMP(slot) do {} while (0)
-#endif
 constexpr int T2_THREADS = 512;
 constexpr int T2_BM = 256, T2_BN = 256;
 constexpr int T2_HALF_BYTES = 128 * BK * 2;             // 16 KiB
@@ -1352,6 +1360,7 @@ __device__ __forceinline__ bf16x8 read_frag3(const char* lds_tile, int row_base,
 template <bool A_KM, bool B_KM, bool OUT_F32>
 __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    APTAI_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1542,6 +1551,7 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
     // ------------------------------------------------------------------ epilogue (same scheme as gemm_kernel)
     // 128 x 192 outputs = 3072 chunks of 8 columns = 6 passes x 512 threads; chunk c -> row c / 24, column 8 * (c % 24)
     // compiled per flag word, indices through opaque copies (see gemm_tile_body)
+    APTAI_STAMP(2);
     int tid_e = tid, lane_e = lane, m0_e = __builtin_amdgcn_readfirstlane(m0), n0_e = __builtin_amdgcn_readfirstlane(n0);
     asm volatile("" : "+v"(tid_e), "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));
     const int fx = epi_flag_word(g);
@@ -1612,6 +1622,11 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
     };
     if (OUT_F32) body(EpiWord<-1>{});
     else epi_dispatch(fx, body);
+    APTAI_STAMP(3);
+#ifdef APTAI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    APTAI_STAMP(4);
+#endif
 }
 
 template <bool A_KM, bool B_KM, bool OUT_F32>
