@@ -182,10 +182,14 @@ __device__ __forceinline__ void epilogue_chunk(float (&v)[8], const GemmArgs& g,
         }
     }
     if (flags & APTAI_EPI_DROPOUT) {
+        // the chunk starts at a multiple of 8 (n % 8 == 0, N % 8 == 0: 16-byte stores), so the four pairs share the folded high
+        // word of drop_hash_pair and their low words are consecutive: same masks, without 64-bit arithmetic and a quarter-rate
+        // 32-bit multiply per pair
         const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+        const uint32_t e_lo = (uint32_t)(e >> 1), e_hi = (uint32_t)(e >> 33) * 0x85ebca6bu;
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
-            const uint32_t hsh = drop_hash_pair(e + r, sd0, sd1);
+            const uint32_t hsh = rng_hash((e_lo + (uint32_t)(r >> 1)) ^ e_hi, sd0, sd1);
             const float k0 = (hsh & 0xffffu) >= g.thr16 ? g.dscale : 0.f, k1 = (hsh >> 16) >= g.thr16 ? g.dscale : 0.f;
             v[r] *= k0;
             v[r + 1] *= k1;
