@@ -109,6 +109,7 @@ __device__ __forceinline__ void gelu_fast_both(float x, float& y, float& dy) {
 // the descriptor's flags plus two internal bits for what the descriptor says with pointers / counts.
 constexpr int EPX_PRE = 1 << 16;                               // out_pre != nullptr
 constexpr int EPX_CS = 1 << 17;                                // colscale_n > 0
+constexpr int EPX_RUNTIME = 1 << 18;                           // set by the host under APTAI_EPI_RUNTIME=1 (A/B): matches no compiled word
 __device__ __forceinline__ int epi_flag_word(const GemmArgs& g) {
     return g.flags | (g.out_pre ? EPX_PRE : 0) | (g.colscale_n > 0 ? EPX_CS : 0);
 }
@@ -625,17 +626,20 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
         const int cl = (tid_e & 15) * 8;                     // column inside the tile, fixed per thread
         const int n = n0_e + cl;
         const bool n_ok = n < g.N;
-        u32x4 resv[NPASS], auxv[NPASS];
-        if (!OUT_F32) {
-    #pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                const int m = m0_e + pass * 16 + (tid_e >> 4);
-                const bool ok = n_ok && m < g.M;
-                resv[pass] = (u32x4){0u, 0u, 0u, 0u};
-                auxv[pass] = (u32x4){0u, 0u, 0u, 0u};
-                if (ok && (flags & APTAI_EPI_RESIDUAL)) resv[pass] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
-                if (ok && (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX))) auxv[pass] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
-            }
+        // residual / aux rows of all passes, issued ahead of the LDS staging - in the compiled bodies that read them; the run-time form
+        // (a flag word nobody listed) loads them pass by pass in a rolled loop: it has to fit the register budget, not to be fast
+        constexpr bool PREF = !OUT_F32 && FM >= 0 && (FM & (APTAI_EPI_RESIDUAL | APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) != 0;
+        constexpr int NPF = PREF ? NPASS : 1;
+        u32x4 resv[NPF], auxv[NPF];
+#pragma unroll
+        for (int pass = 0; pass < NPF; ++pass) {
+            const int m = m0_e + pass * 16 + (tid_e >> 4);
+            const bool ok = PREF && n_ok && m < g.M;
+            u32x4 rq = {0u, 0u, 0u, 0u}, aq = {0u, 0u, 0u, 0u};   // values first, one unconditional array store each (no stack arrays)
+            if (ok && (flags & APTAI_EPI_RESIDUAL)) rq = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+            if (ok && (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX))) aq = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+            resv[pass] = rq;
+            auxv[pass] = aq;
         }
         __syncthreads();                                   // every wave is done reading the staging buffers
         {
@@ -664,29 +668,45 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
         const float alpha = (flags & APTAI_EPI_ALPHA) ? g.alpha : 1.0f;
         uint32_t sd0 = g.seed0, sd1 = g.seed1;
         if (flags & APTAI_EPI_DROPOUT) apply_salt(g.salt, sd0, sd1);
-    #pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
+        auto one_pass = [&](const int pass, const u32x4 auxq, const u32x4 resq) __attribute__((always_inline)) {
             const int ml = pass * 16 + (tid_e >> 4);
             const int m = m0_e + ml;
-            if (m >= g.M || !n_ok) continue;
+            if (m >= g.M || !n_ok) return;
             const f32x4 v0 = *(const f32x4*)(smem + ml * EPI_PITCH + cl * 4);
             const f32x4 v1 = *(const f32x4*)(smem + ml * EPI_PITCH + cl * 4 + 16);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    #pragma unroll
+#pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = (flags & (APTAI_EPI_BIAS | APTAI_EPI_ALPHA)) ? fmaf(v[r], alpha, bias8[r]) : v[r];
             if (OUT_F32) {
                 if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder): += res32[m][n..n+7]
                     const float* R = (const float*)g.residual + (long)m * g.ldr + n;
                     const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
-    #pragma unroll
+#pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
                 }
                 float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
                 *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
                 *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                continue;
+                return;
             }
-            epilogue_chunk<FM>(v, g, flags, (long)m, n, auxv[pass], resv[pass], sd0, sd1);
+            epilogue_chunk<FM>(v, g, flags, (long)m, n, auxq, resq, sd0, sd1);
+        };
+        if constexpr (!OUT_F32 && FM < 0) {
+#pragma unroll 1
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int m = m0_e + pass * 16 + (tid_e >> 4);
+                const bool ok = n_ok && m < g.M;
+                u32x4 rq = {0u, 0u, 0u, 0u}, aq = {0u, 0u, 0u, 0u};
+                if (ok && (flags & APTAI_EPI_RESIDUAL)) rq = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
+                if (ok && (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX))) aq = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+                one_pass(pass, aq, rq);
+            }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                one_pass(pass, auxv[PREF ? pass : 0], resv[PREF ? pass : 0]);
+                asm volatile("" ::: "memory");           // keep the passes apart: hoisting every pass's LDS reads costs the third block's
+            }                                            // worth of registers (launch bounds of gemm_kernel)
         }
     };
     if (OUT_F32) body(EpiWord<-1>{});
@@ -699,7 +719,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
 }
 
 template <bool A_KM, bool B_KM, bool OUT_F32>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel(GemmArgs g) {
     gemm_tile_body<A_KM, B_KM, OUT_F32>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), gridDim.y > 1 ? (int)blockIdx.y : -1,
                                         blockIdx.z);
 }
@@ -723,7 +743,7 @@ struct GroupArgs {
 };
 
 template <bool A_KM, bool B_KM, bool OUT_F32>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_grouped_kernel(GroupArgs ga) {
+__global__ __launch_bounds__(NTHREADS, 3) void gemm_grouped_kernel(GroupArgs ga) {
     const int bid = xcd_remap(blockIdx.x, ga.total);
     int pi = 0;
 #pragma unroll
@@ -963,18 +983,25 @@ __device__ __forceinline__ void gemm256_epilogue_body(const GemmArgs& g, char* s
     uint32_t sd0 = g.seed0, sd1 = g.seed1;
     if (!OUT_F32 && (flags & APTAI_EPI_DROPOUT)) apply_salt(g.salt, sd0, sd1);
     const bool want_res = !OUT_F32 && (flags & APTAI_EPI_RESIDUAL), want_aux = !OUT_F32 && (flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX));
-    const int row_in_group = tid >> 5;                  // 16 rows per step, 4 steps per group, 2 groups per pass
-    // residual / aux rows of one group of four steps (16 B per row and thread), issued a group ahead of their use
-    u32x4 resv[2][4], auxv[2][4];
-    auto prefetch = [&](int slot, int pqm, int grp) {
+    const int row_in_step = tid >> 5;                   // 16 rows per step, 8 steps per pass
+    // Steps are read back in groups: all LDS reads (and the residual / aux row loads, one group ahead) of a group are issued before the
+    // arithmetic of its first step.  Four steps per group for the light flag words; two for the heavy ones and the run-time form, whose
+    // arithmetic needs the registers (with four they spilled ~190 VGPRs - and a kernel that needs scratch memory no longer overlaps
+    // cleanly with another queue's kernels: Force_APTAI's pipelined step lost 6 % to it, measured by swapping this file alone).
+    constexpr bool HEAVY = OUT_F32 ? false : (FM < 0 || (FM & (APTAI_EPI_GELU | APTAI_EPI_DROPOUT | APTAI_EPI_DGELU | APTAI_EPI_RESIDUAL | APTAI_EPI_MUL_AUX)) != 0);
+    constexpr bool HEAVIEST = !OUT_F32 && (FM < 0 || ((FM & APTAI_EPI_GELU) && (FM & (APTAI_EPI_DROPOUT | APTAI_EPI_PRE_DGELU))));
+    constexpr int GS = HEAVIEST ? 1 : HEAVY ? 2 : 4, NG = 8 / GS;      // steps per group, groups per pass
+    u32x4 resv[2][GS], auxv[2][GS];
+    auto prefetch = [&](int slot, int pqm, int grp) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int m = m0 + pqm * 128 + (grp * 4 + k) * 16 + row_in_group;
+        for (int k = 0; k < GS; ++k) {
+            const int m = m0 + pqm * 128 + (grp * GS + k) * 16 + row_in_step;
             const bool ok = n_ok && m < g.M;
-            resv[slot][k] = (u32x4){0u, 0u, 0u, 0u};
-            auxv[slot][k] = (u32x4){0u, 0u, 0u, 0u};
-            if (ok && want_res) resv[slot][k] = *(const u32x4*)(g.residual + (long)m * g.ldr + n);
-            if (ok && want_aux) auxv[slot][k] = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);
+            u32x4 rq = {0u, 0u, 0u, 0u}, aq = {0u, 0u, 0u, 0u};   // (values first, ONE unconditional array store each: two conditional
+            if (ok && want_res) rq = *(const u32x4*)(g.residual + (long)m * g.ldr + n);   // stores were merged into a store through a
+            if (ok && want_aux) aq = *(const u32x4*)(g.aux + (long)m * g.ldaux + n);       // selected stack address: scratch memory)
+            resv[slot][k] = rq;
+            auxv[slot][k] = aq;
         }
     };
     if (want_res || want_aux) prefetch(0, 0, 0);
@@ -989,19 +1016,19 @@ __device__ __forceinline__ void gemm256_epilogue_body(const GemmArgs& g, char* s
                     *(f32x4*)(smem + epi256_off(wr * 64 + i * 16 + (lane & 15), qn * 32 + wc * 8 + j * 4 + (lane >> 4))) = acc[pqm][qn][i][j];
         __syncthreads();
 #pragma unroll
-        for (int grp = 0; grp < 2; ++grp) {
-            const int cur = (pqm * 2 + grp) & 1;
-            if ((want_res || want_aux) && (pqm * 2 + grp) < 3) prefetch(cur ^ 1, grp ? pqm + 1 : pqm, grp ^ 1);
-            f32x4 v0[4], v1[4];
+        for (int grp = 0; grp < NG; ++grp) {
+            const int q = pqm * NG + grp, cur = q & 1;
+            if ((want_res || want_aux) && q + 1 < 2 * NG) prefetch(cur ^ 1, (q + 1) / NG, (q + 1) % NG);
+            f32x4 v0[GS], v1[GS];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int lr = (grp * 4 + k) * 16 + row_in_group;
+            for (int k = 0; k < GS; ++k) {
+                const int lr = (grp * GS + k) * 16 + row_in_step;
                 v0[k] = *(const f32x4*)(smem + epi256_off(lr, 2 * L));
                 v1[k] = *(const f32x4*)(smem + epi256_off(lr, 2 * L + 1));
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int m = m0 + pqm * 128 + (grp * 4 + k) * 16 + row_in_group;
+            for (int k = 0; k < GS; ++k) {
+                const int m = m0 + pqm * 128 + (grp * GS + k) * 16 + row_in_step;
                 if (m >= g.M || !n_ok) continue;
                 float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
                 if (flags & (APTAI_EPI_BIAS | APTAI_EPI_ALPHA)) {
@@ -1022,6 +1049,7 @@ __device__ __forceinline__ void gemm256_epilogue_body(const GemmArgs& g, char* s
                 }
                 epilogue_chunk<FM>(v, g, flags, (long)m, n, auxv[cur][k], resv[cur][k], sd0, sd1);
             }
+            if (HEAVY) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -1812,6 +1840,8 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     // 71.5 -> 76.7 us, FFN2 dgrad 63.6 -> 67.1, QKV forward 45.7 -> 48.8): their co-resident tiles then share B panels but
     // spread over 8 A panels, and A is the operand they re-read most
     if (g.raster_gm < 0) g.raster_gm = ((d->a_kmajor && d->b_kmajor) || tile == 192 || tile == 256 || tile == 257) ? 8 : 0;
+    static const bool epi_runtime = getenv("APTAI_EPI_RUNTIME") && atoi(getenv("APTAI_EPI_RUNTIME")) != 0;
+    if (epi_runtime) g.flags |= EPX_RUNTIME;
     if (!f32) epi_trace(g, tile);
     int rc;
     if (tile == 257) {
