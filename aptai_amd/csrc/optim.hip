@@ -32,9 +32,16 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
     if (base >= n || g == nullptr) return;
     // bias corrections of this parameter's own step count (parameters skipped by LayerDrop lag behind), in double like
     // the Python reference; every thread computes the same two values
-    const double step = (double)dyn[1];
-    a.bc1 = (float)(1.0 - pow((double)a.beta1, step));
-    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, step));
+    // (one lane per block evaluates the two double-precision powers - 256 threads each did, ~200 instructions beside 16 elements of work)
+    __shared__ float bc[2];
+    if (threadIdx.x == 0) {
+        const double step = (double)dyn[1];
+        bc[0] = (float)(1.0 - pow((double)a.beta1, step));
+        bc[1] = (float)sqrt(1.0 - pow((double)a.beta2, step));
+    }
+    __syncthreads();
+    a.bc1 = bc[0];
+    a.bc2_sqrt = bc[1];
     float* p = (float*)job[0];
     float* m = (float*)job[1];
     float* v = (float*)job[2];
@@ -42,12 +49,20 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamArgs a) {
     const bool copy_f32 = job[5] != 0;
     const bool vec = (n % 4 == 0) && ((job[0] | job[1] | job[2] | dyn[0]) % 16 == 0) && (job[3] % 8 == 0);
     if (vec) {
+        // all 16 loads of the thread's four chunks first: the pointers may alias as far as the compiler knows, so a rolled form waits
+        // for chunk k's stores before it issues chunk k + 1's loads
+        f32x4 pq[4], mq[4], vq[4], gq[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long i = base + (long)(it * 256 + threadIdx.x) * 4;
+            if (i < n) { pq[it] = *(const f32x4*)(p + i); mq[it] = *(const f32x4*)(m + i); vq[it] = *(const f32x4*)(v + i); gq[it] = *(const f32x4*)(g + i); }
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const long i = base + (long)(it * 256 + threadIdx.x) * 4;
             if (i >= n) break;
-            f32x4 pp = *(const f32x4*)(p + i), mm = *(const f32x4*)(m + i), vv = *(const f32x4*)(v + i);
-            const f32x4 gg = *(const f32x4*)(g + i);
+            f32x4 pp = pq[it], mm = mq[it], vv = vq[it];
+            const f32x4 gg = gq[it];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float mr = mm[r], vr = vv[r];
