@@ -1834,12 +1834,12 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     if (tile == 257) APTAI_REQUIRE(sk_ok, "aptai_gemm_bf16: tile 257 (stream-K) needs sk_workspace (aptai_gemm_sk_workspace_bytes), no batching / "
                                           "split-K / accumulate and M, N >= 256");
     if (tile == 64 && d->a_kmajor) tile = 128;            // 64-row tiles need a K-contiguous A
-    // 2-D rasterisation per kernel, measured in the step (rocprofv3 kernel statistics, one box, raster 0 / 8): it pays where both
-    // operands are K-major (weight gradients: 146.6 -> 131.8 us for a layer's grouped launch) and marginally in the 192- / 256-tile
-    // kernels (36.1 -> 35.3, 195.9 -> 193.8 us); the 128- and 64-row kernels with a K-contiguous A LOSE 5-7 % with it (FFN1 forward
-    // 71.5 -> 76.7 us, FFN2 dgrad 63.6 -> 67.1, QKV forward 45.7 -> 48.8): their co-resident tiles then share B panels but
-    // spread over 8 A panels, and A is the operand they re-read most
-    if (g.raster_gm < 0) g.raster_gm = ((d->a_kmajor && d->b_kmajor) || tile == 192 || tile == 256 || tile == 257) ? 8 : 0;
+    // 2-D rasterisation (tile groups of 8 rows per XCD) for every kernel.  Rounds 2 and 3a kept the row-major walk for the 128- and 64-row
+    // kernels with a K-contiguous A, which then LOST 5-7 % to the raster (FFN1 forward 71.5 -> 76.7 us) while it cut their fabric-side
+    // re-reads (FFN1: 129 MB fetched for 17 MB of operands); with the per-flag-word epilogues the balance is the other way: per forced
+    // 128-row tile FFN1 forward 61.5-64.2 -> 59.3 us, FFN2 dgrad 50.4 -> 48.8 us, the layer's ten bf16-output GEMMs 388-392 -> 382-383 us
+    // (tools/step_gemm_tiles.py, APTAI_GEMM_RASTER = -1 / 4 / 8 / 16 in one call; 64-row tiles 425 -> 416 us).  APTAI_GEMM_RASTER=0 = row-major.
+    if (g.raster_gm < 0) g.raster_gm = 8;
     static const bool epi_runtime = getenv("APTAI_EPI_RUNTIME") && atoi(getenv("APTAI_EPI_RUNTIME")) != 0;
     if (epi_runtime) g.flags |= EPX_RUNTIME;
     if (!f32) epi_trace(g, tile);
