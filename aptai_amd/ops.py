@@ -249,6 +249,20 @@ def gemm_mxfp8(aq, a_s, bq, b_s, M, N, K, *, bias=None, gelu=False, residual=Non
     return out
 
 
+def gemm_mxfp8_mxout(aq, a_s, bq, b_s, M, N, K, *, bias=None, gelu=False, out=None):
+    """(q uint8 [M][N], scales uint8 [M][N/32]) = mx_quantize(bf16(dequant(A) . dequant(B)^T + bias [-> GELU])) in one launch
+    (aptai_gemm_mxfp8_mxout): the next MX GEMM's A operand without the bf16 tensor in between."""
+    _dev(aq, a_s, bq, b_s, bias)
+    if out is None:
+        q = torch.empty((M, N), device=aq.device, dtype=torch.uint8)
+        s = torch.empty((M, N // 32), device=aq.device, dtype=torch.uint8)
+    else:
+        q, s = out
+    _lib.call("aptai_gemm_mxfp8_mxout", aq.data_ptr(), a_s.data_ptr(), aq.stride(0), a_s.stride(0), bq.data_ptr(), b_s.data_ptr(), bq.stride(0),
+              b_s.stride(0), q.data_ptr(), q.stride(0), s.data_ptr(), s.stride(0), _ptr(bias), int(gelu), M, N, K, _stream())
+    return q, s
+
+
 # ----------------------------------------------------------------------------- exact (fp32-class) inference path
 def split_f32(x32: torch.Tensor, pieces: int, *, weight_side: bool = False, gelu: bool = False, rows=None, cols=None, ldx=None) -> torch.Tensor:
     """fp32 [rows][cols] -> bf16 pieces [rows][cols * pieces] in the K-tile-interleaved layout of aptai_split_f32."""

@@ -291,6 +291,12 @@ int aptai_mx_quantize_bf16(const void* x, int64_t ldx, void* q, int64_t ldq, voi
 int aptai_gemm_mxfp8(const void* A, const void* A_scales, int64_t lda, int64_t ldas, const void* B, const void* B_scales, int64_t ldb,
                      int64_t ldbs, void* C, int64_t ldc, const float* bias, int gelu, const void* residual, int64_t ldr, int64_t M,
                      int64_t N, int64_t K, void* stream);
+/* The same product with an MXFP8 RESULT (elements Cq [M][ldcq], scales C_scales [M][ldcs], N % 32 == 0): bit-identical to aptai_gemm_mxfp8
+ * followed by aptai_mx_quantize_bf16 of its bf16 output, without that tensor's trip through HBM - the FFN1 -> FFN2 hand-over of the
+ * encoder layer (HF:556-572: intermediate_dense + GELU feeding output_dense). */
+int aptai_gemm_mxfp8_mxout(const void* A, const void* A_scales, int64_t lda, int64_t ldas, const void* B, const void* B_scales, int64_t ldb,
+                           int64_t ldbs, void* Cq, int64_t ldcq, void* C_scales, int64_t ldcs, const float* bias, int gelu, int64_t M,
+                           int64_t N, int64_t K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ CTC
  * log_softmax + CTC negative log-likelihood (alpha recursion) and its gradient w.r.t. the LOGITS (beta recursion),

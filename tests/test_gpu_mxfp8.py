@@ -64,6 +64,26 @@ def test_mx_gemm_equals_the_product_of_the_dequantised_operands(M, N, K, gelu, r
         assert rel < 6e-2, rel
 
 
+@pytest.mark.parametrize("M,N,K,gelu", [(256, 384, 256, False), (300, 3072, 768, True), (3000, 4096, 1024, True)])
+def test_mx_gemm_with_mx_output_is_the_gemm_followed_by_the_quantiser(M, N, K, gelu):
+    """aptai_gemm_mxfp8_mxout (FFN1 -> FFN2 hand-over) against its definition: the bf16 GEMM result, quantised - every element code and
+    every scale byte equal (the epilogue rounds to bf16 before it quantises; M = 300 / 3000 leave a ragged last tile)."""
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).cuda()
+    aq, a_s = ops.mx_quantize(a.cuda())
+    wq, w_s = ops.mx_quantize(w.cuda())
+    want_q, want_s = ops.mx_quantize(ops.gemm_mxfp8(aq, a_s, wq, w_s, M, N, K, bias=bias, gelu=gelu))
+    got_q, got_s = ops.gemm_mxfp8_mxout(aq, a_s, wq, w_s, M, N, K, bias=bias, gelu=gelu)
+    torch.cuda.synchronize()
+    assert torch.equal(got_s.cpu(), want_s.cpu())
+    gq, wq_ = got_q.cpu(), want_q.cpu()
+    nz = ~((gq == wq_) | ((gq & 0x7F) == 0) & ((wq_ & 0x7F) == 0))               # +0 and -0 both encode zero
+    assert not nz.any(), f"{int(nz.sum())} element codes differ"
+
+
 def test_force_aptai_with_the_mxfp8_encoder_against_the_oracle():
     """Force_APTAI (large shape, reduced depth) with the frozen encoder's Linear layers in MXFP8: the same gate as the bf16 path -
     alignment indices exact wherever the oracle's margin exceeds the measured row noise - with the fraction of frames inside the
