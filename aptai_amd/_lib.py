@@ -87,6 +87,7 @@ ARGTYPES = {
     "aptai_ctc_greedy_decode": [_P, _I64, _I64, _I64, _I64, _I64, _I, _P, _I64, _P, _P],
     "aptai_mx_quantize_bf16": [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _P],
     "aptai_gemm_mxfp8": [_P, _P, _I64, _I64, _P, _P, _I64, _I64, _P, _I64, _P, _I, _P, _I64, _I64, _I64, _I64, _P],
+    "aptai_layernorm_fwd_mx": [_P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _F, _P],
     "aptai_gemm_mxfp8_mxout": [_P, _P, _I64, _I64, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _P, _I, _I64, _I64, _I64, _P],
     "aptai_split_f32": [_P, _I64, _I64, _I64, _I, _I, _I, _P, _I64, _P],
     "aptai_bias_act_res_f32": [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _P, _I64, _P],

@@ -54,11 +54,17 @@ __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict
     }
 }
 
-template <int NCH>   // cols = NCH * 256
+// MX = true: the result also (or only: y may be null) leaves as MXFP8 - E4M3 elements q + one E8M0 scale per 32 columns - the A operand
+// of the fp8 encoder's q|k|v / FFN1 GEMMs (csrc/mxgemm.hip) without the quantiser's own pass.  Bit-identical to the MX = false kernel
+// followed by mx_quantize_kernel: it IS the same kernel up to the store (statistics from the same instruction sequence - a separately
+// written copy differed in one bf16 value per 3 M), and the normalised values are rounded to bf16 before they are quantised.  A lane
+// holds 4 consecutive columns per 256-column chunk, so a 32-column block is 8 neighbouring lanes.
+template <int NCH, bool MX = false>   // cols = NCH * 256
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long rows,
-                                                     float eps, int gelu_after) {
+                                                     float eps, int gelu_after, uint8_t* __restrict__ mq = nullptr, long ldq = 0,
+                                                     uint8_t* __restrict__ msc = nullptr, long lds = 0) {
     constexpr int COLS = NCH * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float gm[NCH][4], bt[NCH][4];
@@ -92,10 +98,27 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
             float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                o[r] = (v[j][r] - mu) * rs * gm[j][r] + bt[j][r];
+                o[r] = fmaf((v[j][r] - mu) * rs, gm[j][r], bt[j][r]);      // (spelled out: ln_fwd_mx_kernel must round the same way)
                 if (gelu_after) o[r] = gelu_fast(o[r]);
             }
-            *(u32x2*)(yr + (j * 64 + lane) * 4) = (u32x2){pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            const u32x2 packed = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            if (!MX || y) *(u32x2*)(yr + (j * 64 + lane) * 4) = packed;
+            if (MX) {
+                o[0] = lo_bf(packed[0]); o[1] = hi_bf(packed[0]); o[2] = lo_bf(packed[1]); o[3] = hi_bf(packed[1]);
+                float amax = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+                int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;   // as mx_quantize_kernel: 2^(floor(log2 amax) - 8), biased
+                e = e < 1 ? 1 : (e > 254 ? 254 : e);
+                const float inv = __uint_as_float((uint32_t)(254 - e) << 23);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = __builtin_amdgcn_fmed3f(o[r] * inv, -448.f, 448.f);
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], w, true);
+                *(uint32_t*)(mq + row * ldq + (j * 64 + lane) * 4) = (uint32_t)w;
+                if ((lane & 7) == 0) msc[row * lds + ((j * 64 + lane) >> 3)] = (uint8_t)e;
+            }
         }
         if (lane == 0) {
             if (mean) mean[row] = mu;
@@ -279,6 +302,27 @@ extern "C" int aptai_layernorm_fwd(const void* x, const float* gamma, const floa
     }
 #undef LN_FWD
     APTAI_CHECK_LAUNCH("ln_fwd_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_layernorm_fwd_mx(const void* x, const float* gamma, const float* beta, void* y_bf16, void* q, int64_t ldq,
+                                      void* scales, int64_t lds, int64_t rows, int64_t cols, float eps, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APTAI_REQUIRE(x && gamma && beta && q && scales, "aptai_layernorm_fwd_mx: null pointer");
+    APTAI_REQUIRE(rows > 0 && cols % 256 == 0 && cols >= 256 && cols <= 1024, "aptai_layernorm_fwd_mx: rows=%ld cols=%ld (cols: 256..1024, %%256)",
+                  (long)rows, (long)cols);
+    APTAI_REQUIRE(ldq >= cols && ldq % 4 == 0 && (uintptr_t)q % 4 == 0 && lds >= cols / 32, "aptai_layernorm_fwd_mx: output rows must keep 4-byte alignment");
+    long blocks = ceil_div(rows, 4);
+    if (blocks > 2048) blocks = 2048;
+#define LN_MX(NCH) APTAI_LAUNCH((ln_fwd_kernel<NCH, true>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y_bf16, (float*)nullptr, (float*)nullptr, (long)rows, eps, 0, (uint8_t*)q, (long)ldq, (uint8_t*)scales, (long)lds)
+    switch (cols / 256) {
+        case 1: LN_MX(1); break;
+        case 2: LN_MX(2); break;
+        case 3: LN_MX(3); break;
+        default: LN_MX(4); break;
+    }
+#undef LN_MX
+    APTAI_CHECK_LAUNCH("ln_fwd_kernel<MX>");
     return APTAI_OK;
 }
 

@@ -249,6 +249,18 @@ def gemm_mxfp8(aq, a_s, bq, b_s, M, N, K, *, bias=None, gelu=False, residual=Non
     return out
 
 
+def layernorm_fwd_mx(x, gamma, beta, eps, *, want_bf16=False):
+    """nn.LayerNorm -> (bf16 | None, q uint8 [rows][cols], scales uint8 [rows][cols/32]) in one launch (aptai_layernorm_fwd_mx)."""
+    _dev(x, gamma, beta)
+    rows, cols = x.shape
+    y = torch.empty_like(x) if want_bf16 else None
+    q = torch.empty((rows, cols), device=x.device, dtype=torch.uint8)
+    s = torch.empty((rows, cols // 32), device=x.device, dtype=torch.uint8)
+    _lib.call("aptai_layernorm_fwd_mx", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(y), q.data_ptr(), q.stride(0), s.data_ptr(), s.stride(0),
+              rows, cols, eps, _stream())
+    return y, q, s
+
+
 def gemm_mxfp8_mxout(aq, a_s, bq, b_s, M, N, K, *, bias=None, gelu=False, out=None):
     """(q uint8 [M][N], scales uint8 [M][N/32]) = mx_quantize(bf16(dequant(A) . dequant(B)^T + bias [-> GELU])) in one launch
     (aptai_gemm_mxfp8_mxout): the next MX GEMM's A operand without the bf16 tensor in between."""

@@ -209,16 +209,17 @@ class _LayerImpl:
         M, H, I = g.M, cfg.hidden_size, cfg.intermediate_size
         ln1w, ln1b, ln2w, ln2b = params[0], params[1], params[2], params[3]
         pre = cfg.do_stable_layer_norm
-        attn_in = ops.layernorm_fwd(x, ln1w, ln1b, cfg.layer_norm_eps, save_stats=False)[0] if pre else x
-        aq, a_s = ops.mx_quantize(attn_in)
+        if pre:             # the normalised rows feed the q|k|v GEMM only: they leave the LayerNorm kernel as MXFP8
+            _, aq, a_s = ops.layernorm_fwd_mx(x, ln1w, ln1b, cfg.layer_norm_eps)
+        else:
+            aq, a_s = ops.mx_quantize(x)
         qkv = ops.gemm_mxfp8(aq, a_s, mx.wqkv[0], mx.wqkv[1], M, 3 * H, H, bias=w.bqkv)
         ctx, _ = ops.attention_fwd(qkv, self.lens, g.B, g.Tp, H, cfg.num_attention_heads, save_lse=False)
         s1 = ops.gemm(ctx, w.wo, M, H, H, bias=w.bo, residual=x)
-        if pre:
-            ffn_in = ops.layernorm_fwd(s1, ln2w, ln2b, cfg.layer_norm_eps, save_stats=False)[0]
-        else:
-            ffn_in = ops.layernorm_fwd(s1, ln1w, ln1b, cfg.layer_norm_eps, save_stats=False)[0]
-        fq, f_s = ops.mx_quantize(ffn_in)
+        if pre:             # FFN1's input only
+            ffn_in, fq, f_s = ops.layernorm_fwd_mx(s1, ln2w, ln2b, cfg.layer_norm_eps)
+        else:               # post-LN: also the residual of FFN2
+            ffn_in, fq, f_s = ops.layernorm_fwd_mx(s1, ln1w, ln1b, cfg.layer_norm_eps, want_bf16=True)
         hq, h_s = ops.gemm_mxfp8_mxout(fq, f_s, mx.w1[0], mx.w1[1], M, I, H, bias=w.b1, gelu=True)
         s2 = ops.gemm_mxfp8(hq, h_s, mx.w2[0], mx.w2[1], M, H, I, bias=w.b2, residual=s1 if pre else ffn_in)
         y = s2 if pre else ops.layernorm_fwd(s2, ln2w, ln2b, cfg.layer_norm_eps, save_stats=False)[0]

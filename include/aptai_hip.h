@@ -294,6 +294,10 @@ int aptai_gemm_mxfp8(const void* A, const void* A_scales, int64_t lda, int64_t l
 /* The same product with an MXFP8 RESULT (elements Cq [M][ldcq], scales C_scales [M][ldcs], N % 32 == 0): bit-identical to aptai_gemm_mxfp8
  * followed by aptai_mx_quantize_bf16 of its bf16 output, without that tensor's trip through HBM - the FFN1 -> FFN2 hand-over of the
  * encoder layer (HF:556-572: intermediate_dense + GELU feeding output_dense). */
+/* nn.LayerNorm (HF:500,556 of the pre-LN layer) whose result leaves as MXFP8 (q [rows][ldq], scales [rows][lds], one per 32 columns) and,
+ * if y_bf16 is not null, as bf16 too: bit-identical to aptai_layernorm_fwd followed by aptai_mx_quantize_bf16. */
+int aptai_layernorm_fwd_mx(const void* x, const float* gamma, const float* beta, void* y_bf16, void* q, int64_t ldq, void* scales,
+                           int64_t lds, int64_t rows, int64_t cols, float eps, void* stream);
 int aptai_gemm_mxfp8_mxout(const void* A, const void* A_scales, int64_t lda, int64_t ldas, const void* B, const void* B_scales, int64_t ldb,
                            int64_t ldbs, void* Cq, int64_t ldcq, void* C_scales, int64_t ldcs, const float* bias, int gelu, int64_t M,
                            int64_t N, int64_t K, void* stream);

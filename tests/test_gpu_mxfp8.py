@@ -84,6 +84,25 @@ def test_mx_gemm_with_mx_output_is_the_gemm_followed_by_the_quantiser(M, N, K, g
     assert not nz.any(), f"{int(nz.sum())} element codes differ"
 
 
+@pytest.mark.parametrize("rows,cols,want_bf16", [(37, 768, True), (3000, 1024, False), (8192, 768, False)])
+def test_layernorm_with_mx_output_is_layernorm_followed_by_the_quantiser(rows, cols, want_bf16):
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(rows, cols, generator=g) * 2.0 + 0.3).to(torch.bfloat16).cuda()
+    gamma, beta = (1.0 + 0.1 * torch.randn(cols, generator=g)).cuda(), (0.1 * torch.randn(cols, generator=g)).cuda()
+    y_ref = ops.layernorm_fwd(x, gamma, beta, 1e-5, save_stats=False)[0]
+    want_q, want_s = ops.mx_quantize(y_ref)
+    y, q, s = ops.layernorm_fwd_mx(x, gamma, beta, 1e-5, want_bf16=want_bf16)
+    torch.cuda.synchronize()
+    assert (y is not None) == want_bf16
+    if want_bf16:
+        assert torch.equal(y.cpu().view(torch.int16), y_ref.cpu().view(torch.int16))
+    assert torch.equal(s.cpu(), want_s.cpu())
+    gq, wq_ = q.cpu(), want_q.cpu()
+    nz = ~((gq == wq_) | ((gq & 0x7F) == 0) & ((wq_ & 0x7F) == 0))
+    assert not nz.any(), f"{int(nz.sum())} element codes differ"
+
+
 def test_force_aptai_with_the_mxfp8_encoder_against_the_oracle():
     """Force_APTAI (large shape, reduced depth) with the frozen encoder's Linear layers in MXFP8: the same gate as the bf16 path -
     alignment indices exact wherever the oracle's margin exceeds the measured row noise - with the fraction of frames inside the
