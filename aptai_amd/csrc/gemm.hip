@@ -63,6 +63,8 @@ struct GemmArgs {
     long slab_stride;           // elements between split-K slabs (fp32 out only)
     int tiles_m, tiles_n;
     int raster_gm;              // tile rows per raster group (raster2d); 0 = row-major walk
+    long hash_ld; int hash_n0;  // dropout element index = m * hash_ld + hash_n0 + n: a launch that covers columns [hash_n0, hash_n0 + N) of a
+                                // wider output (aptai_gemm_bf16 splits some) draws the masks of the whole one
     int colscale_n; float colscale;   // columns [0, colscale_n) of the bf16 output are multiplied by colscale (after alpha / bias)
     // 2-level batching: blockIdx.y = outer * nb_inner + inner; element offsets per level
     int nb_inner;
@@ -186,7 +188,7 @@ __device__ __forceinline__ void epilogue_chunk(float (&v)[8], const GemmArgs& g,
         // the chunk starts at a multiple of 8 (n % 8 == 0, N % 8 == 0: 16-byte stores), so the four pairs share the folded high
         // word of drop_hash_pair and their low words are consecutive: same masks, without 64-bit arithmetic and a quarter-rate
         // 32-bit multiply per pair
-        const uint64_t e = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+        const uint64_t e = (uint64_t)m * (uint64_t)g.hash_ld + (uint64_t)(g.hash_n0 + n);
         const uint32_t e_lo = (uint32_t)(e >> 1), e_hi = (uint32_t)(e >> 33) * 0x85ebca6bu;
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
@@ -1723,6 +1725,7 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     if (g.thr16 == 0) g.flags &= ~APTAI_EPI_DROPOUT;
     g.alpha = d->alpha;
     g.colscale_n = d->colscale_n; g.colscale = d->colscale;
+    g.hash_ld = d->N; g.hash_n0 = 0;
     g.tiles_m = (int)ceil_div(d->M, BM);
     g.tiles_n = (int)ceil_div(d->N, BN);
     {
@@ -1769,12 +1772,48 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     return APTAI_OK;
 }
 
+static int gemm_bf16_one(const aptai_gemm_desc* d, void* stream_, long hash_ld, int hash_n0);
+
 extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
+    // Outputs that make x.5 rounds of 256 x 256 tiles (base FFN1 forward / FFN2 dgrad: 8192 x 3072 = 384 tiles on 256 CUs) run as TWO
+    // launches over column ranges: whole rounds of 256-row tiles (0.63 of the MFMA rate in the loop), then the remainder as one round of
+    // 128-row tiles - instead of three rounds of 128-row tiles (0.34).  Measured both ways in one call: standalone the single launch is the
+    // faster one since the 128-row kernels walk the tiles in 2-D groups (FFN1 forward 56-58 vs 60.8 us), in the step the split is (8.82-8.85
+    // -> 8.78-8.79 ms, three interleaved pairs): kept on, APTAI_GEMM_SPLITN=0 turns it off.  Bit-identical outputs and dropout masks
+    // (tests/test_gpu_gemm.py: a tile's K walk does not depend on its size; the element index is the whole output's, hash_ld / hash_n0).
+    static const bool split_on = !(getenv("APTAI_GEMM_SPLITN") && atoi(getenv("APTAI_GEMM_SPLITN")) == 0);
+    if (split_on && d != nullptr && d->tile == 0 && !d->out_f32 && !d->a_kmajor && d->split_k <= 1 && !d->accumulate && d->batch_outer <= 1 &&
+        d->batch_inner <= 1 && d->colscale_n == 0 && d->sk_workspace == nullptr && d->M % 256 == 0 && d->N % 256 == 0 && d->K <= 1024 &&
+        getenv("APTAI_GEMM_TILE") == nullptr) {
+        const long tm = d->M / 256, tn = d->N / 256, T = tm * tn;
+        if (T > 256 && T % 256 == 128 && (T - 128) % tm == 0) {
+            const long n1 = (T - 128) / tm * 256, rem = d->N - n1;
+            if ((d->M / 128) * (rem / 128) <= 512) {
+                aptai_gemm_desc a = *d, b = *d;
+                a.N = n1; a.tile = 256;
+                b.N = rem; b.tile = 128;
+                b.B = (const char*)d->B + (d->b_kmajor ? n1 * 2 : n1 * d->ldb * 2);
+                b.C = (char*)d->C + n1 * 2;
+                if (d->out_pre) b.out_pre = (char*)d->out_pre + n1 * 2;
+                if (d->bias) b.bias = d->bias + n1;
+                if (d->residual) b.residual = (const char*)d->residual + n1 * 2;
+                if (d->aux) b.aux = (const char*)d->aux + n1 * 2;
+                const int rc = gemm_bf16_one(&a, stream_, d->N, 0);
+                if (rc != APTAI_OK) return rc;
+                return gemm_bf16_one(&b, stream_, d->N, (int)n1);
+            }
+        }
+    }
+    return gemm_bf16_one(d, stream_, d ? d->N : 0, 0);
+}
+
+static int gemm_bf16_one(const aptai_gemm_desc* d, void* stream_, long hash_ld, int hash_n0) {
     hipStream_t stream = (hipStream_t)stream_;
     GemmArgs g;
     int nbatch = 1, nsplit = 1;
     const int brc = build_args(d, g, nbatch, nsplit, stream_);
     if (brc != APTAI_OK) return brc;
+    g.hash_ld = hash_ld; g.hash_n0 = hash_n0;
     const bool f32 = d->out_f32 != 0;
     float* final_out = (float*)d->C;
     // tile selection: the 256x256 deep-pipelined kernel when the grid still fills the chip, else 128x128 (2 blocks/CU)
