@@ -520,6 +520,169 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(Conv0BwdArgs a) {
     }
 }
 
+// ---- pass A of the group mode on the fp32 matrix pipe: same layout as conv0_bwd_weight_mfma_kernel below (read its comment first) -
+// contraction (1) gives xhat^T with the frames on the registers, the vector pipe forms dgn = dy * gelu'(gamma xhat + beta) and each lane
+// accumulates sum_f dgn and sum_f dgn * xhat of its 8 channels over its frames; the four frame quarters of a channel (lanes q = 0..3) meet
+// in two shuffles at the end.  Writes the same [B][nchunks][2][512] partials as conv0_bwd_group_stats_kernel.
+__global__ __launch_bounds__(256) void conv0_bwd_group_stats_mfma_kernel(Conv0BwdArgs a) {
+    const Conv0Args& f = a.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int c0 = 128 * wave + 8 * j;
+    float w1[8][3], gm[8], bt[8], s1[8], s2[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int c = c0 + g;
+        const float mu = f.stats[((long)b * 2 + 0) * C0 + c], rs = f.stats[((long)b * 2 + 1) * C0 + c];
+        gm[g] = f.gamma[c]; bt[g] = f.beta[c];
+        s1[g] = s2[g] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = 4 * s + q;
+            w1[g][s] = k < KW ? f.w[c * KW + k] * rs : (k == KW ? ((f.bias ? f.bias[c] : 0.f) - mu) * rs : 0.f);
+        }
+    }
+    const float* xb = f.audio + (long)b * f.S;
+    const bf16_t* dyb = a.dy + (long)b * f.T_alloc * C0 + c0;
+    const long last = f.S - 1;
+    const int tb = chunk * BWD_FRAMES_PER_BLOCK;
+    int t1 = tb + BWD_FRAMES_PER_BLOCK;
+    t1 = t1 < f.T_real ? t1 : f.T_real;
+    for (int t0 = tb; t0 < t1; t0 += 16) {
+        float x1[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = 4 * s + q;
+            long idx = (long)(t0 + j) * STRIDE + k;
+            idx = idx < last ? idx : last;
+            const float v = xb[idx];
+            x1[s] = k < KW ? v : (k == KW ? 1.0f : 0.f);
+        }
+        u32x4 dq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + 4 * q + r;
+            dq[r] = *(const u32x4*)(dyb + (long)(t < f.T_alloc ? t : f.T_alloc - 1) * C0);
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 xh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) xh = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[s], w1[g][s], xh, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t pair = dq[r][g >> 1];
+                const float d = (g & 1) ? hi_bf(pair) : lo_bf(pair);
+                float dgn = d * gelu_fast_grad(fmaf(xh[r], gm[g], bt[g]));
+                dgn = (t0 + 4 * q + r < t1) ? dgn : 0.f;
+                s1[g] += dgn;
+                s2[g] = fmaf(dgn, xh[r], s2[g]);
+            }
+        }
+    }
+    float* out = a.gpart + ((long)b * f.nchunks + chunk) * 2 * C0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float u = s1[g], v = s2[g];
+        u += __shfl_xor(u, 16, 64); v += __shfl_xor(v, 16, 64);
+        u += __shfl_xor(u, 32, 64); v += __shfl_xor(v, 32, 64);
+        if (q == 0) { out[c0 + g] = u; out[C0 + c0 + g] = v; }
+    }
+}
+
+// ---- pass B of the group mode on the fp32 MATRIX pipe.  conv0_bwd_weight_kernel<0> spends ~45 vector issue slots per output element
+// (10 conv FMAs to recompute it, the norm / GELU derivative, 11 FMAs into the tap accumulators): 629 us per call at 16 x 10 s, six
+// times its HBM floor (the 524 MB of dy).  Here both contractions run as v_mfma_f32_16x16x4_f32 blocks and the vector pipe keeps
+// only the ~20 slots of the derivative:
+//   (1) xhat^T[f][c]  = sum_k x~[f][k] w'[k][c]      A = waveform window (16 frames x 12), B = taps folded with rstd and the shift
+//                        (k = 10: (bias - mean) rstd against x~ = 1, k = 11: 0): the NORMALISED conv output, frames on the registers
+//   (2) dW^T[k][c]   += sum_f x^T[k][f] du[f][c]     register r of the lane that holds frames 4 q + r of (1) IS the B operand of K-step
+//                        r (frames {r, 4 + r, 8 + r, 12 + r}); A = x[5 (t0 + 4 q + r) + k], k = 10: 1.0 -> dbias, k >= 11: 0
+// One wave = one quarter of the channels (8 groups of 16) for the block's 256 frames, so the four waves write disjoint channels and
+// nothing is reduced across them.  Channel map c(g, j) = 128 w + 8 j + g: a lane's 8 groups are 8 consecutive channels = one 16-byte
+// dy load per frame row (a wave instruction reads 256-byte row segments).
+__global__ __launch_bounds__(256) void conv0_bwd_weight_mfma_kernel(Conv0BwdArgs a) {
+    const Conv0Args& f = a.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, j = lane & 15;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int c0 = 128 * wave + 8 * j;                   // this lane's 8 channels c0 + g
+    float w1[8][3], gm[8], bt[8], gr[8], m1g[8], m2g[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int c = c0 + g;
+        const float mu = f.stats[((long)b * 2 + 0) * C0 + c], rs = f.stats[((long)b * 2 + 1) * C0 + c];
+        gm[g] = f.gamma[c]; bt[g] = f.beta[c];
+        gr[g] = gm[g] * rs;
+        m1g[g] = gr[g] * a.gmean[((long)b * 2 + 0) * C0 + c];
+        m2g[g] = gr[g] * a.gmean[((long)b * 2 + 1) * C0 + c];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = 4 * s + q;
+            w1[g][s] = k < KW ? f.w[c * KW + k] * rs : (k == KW ? ((f.bias ? f.bias[c] : 0.f) - mu) * rs : 0.f);
+        }
+    }
+    const float* xb = f.audio + (long)b * f.S;
+    const bf16_t* dyb = a.dy + (long)b * f.T_alloc * C0 + c0;
+    const long last = f.S - 1;
+    f32x4 acc[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tb = chunk * BWD_FRAMES_PER_BLOCK;
+    int t1 = tb + BWD_FRAMES_PER_BLOCK;
+    t1 = t1 < f.T_real ? t1 : f.T_real;
+    for (int t0 = tb; t0 < t1; t0 += 16) {
+        // operands of both contractions from the waveform (L1-resident: 16 frames = 85 samples); a software prefetch of the next block's
+        // operands measured 4 % slower (645 -> 674 us for the whole call): the waves of a SIMD already cover each other's loads
+        float x1[3], x2[4];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = 4 * s + q;
+            long idx = (long)(t0 + j) * STRIDE + k;
+            idx = idx < last ? idx : last;
+            const float v = xb[idx];
+            x1[s] = k < KW ? v : (k == KW ? 1.0f : 0.f);
+        }
+        u32x4 dq[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + 4 * q + r;
+            long idx = (long)t * STRIDE + j;
+            idx = idx < last ? idx : last;
+            const float v = xb[idx];
+            x2[r] = j < KW ? v : (j == KW ? 1.0f : 0.f);
+            dq[r] = *(const u32x4*)(dyb + (long)(t < f.T_alloc ? t : f.T_alloc - 1) * C0);
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 xh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 3; ++s) xh = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[s], w1[g][s], xh, 0, 0, 0);
+            float du[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t pair = dq[r][g >> 1];
+                const float d = (g & 1) ? hi_bf(pair) : lo_bf(pair);
+                const float dgn = d * gelu_fast_grad(fmaf(xh[r], gm[g], bt[g]));
+                const float v = fmaf(dgn, gr[g], -fmaf(xh[r], m2g[g], m1g[g]));
+                du[r] = (t0 + 4 * q + r < t1) ? v : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2[r], du[r], acc[g], 0, 0, 0);
+        }
+    }
+    // acc[g][r] = partial of quantity k = 4 q + r (taps 0..9, dbias 10, zeros above) of channel c0 + g
+    float* out = a.wpart + ((long)b * f.nchunks + chunk) * C0 * 13;
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * q + r;
+            if (k < 13) out[(long)(c0 + g) * 13 + k] = acc[g][r];
+        }
+}
+
 // dweight [512][10], dbias [512], (layer mode) dgamma/dbeta [512] = sum over (b, chunk) partials: 64 outputs x 16 partial
 // slices per block, slices combined in LDS in slice order (the serial walk over 8 000 partials took 631 us)
 __global__ __launch_bounds__(1024) void conv0_bwd_reduce_kernel(const float* __restrict__ wpart, int nparts, float* __restrict__ dweight,
@@ -634,12 +797,16 @@ extern "C" int aptai_conv0_bwd(const float* audio, int64_t B, int64_t S, const f
     a.wpart = gmean + (long)B * 2 * C0;
     dim3 grid((unsigned)a.f.nchunks, (unsigned)B);
     if (mode == 0) {
-        APTAI_LAUNCH(conv0_bwd_group_stats_kernel, grid, dim3(256), 0, stream, a);
+        // both passes' contractions on the fp32 matrix pipe (APTAI_CONV0_BWD_MFMA=0: the all-vector kernels, A/B)
+        static const bool bwd_mfma = !(getenv("APTAI_CONV0_BWD_MFMA") && atoi(getenv("APTAI_CONV0_BWD_MFMA")) == 0);
+        if (bwd_mfma) APTAI_LAUNCH(conv0_bwd_group_stats_mfma_kernel, grid, dim3(256), 0, stream, a);
+        else APTAI_LAUNCH(conv0_bwd_group_stats_kernel, grid, dim3(256), 0, stream, a);
         APTAI_CHECK_LAUNCH("conv0_bwd_group_stats_kernel");
         APTAI_LAUNCH(conv0_bwd_group_final_kernel, dim3(C0 / 64), dim3(1024), 0, stream, (const float*)a.gpart, gmean, dgamma, dbeta, (int)B,
                      a.f.nchunks, (int)T_real, (const int*)aptai_frame_bounds((const void*)stream));
         APTAI_CHECK_LAUNCH("conv0_bwd_group_final_kernel");
-        APTAI_LAUNCH(conv0_bwd_weight_kernel<0>, grid, dim3(256), 0, stream, a);
+        if (bwd_mfma) APTAI_LAUNCH(conv0_bwd_weight_mfma_kernel, grid, dim3(256), 0, stream, a);
+        else APTAI_LAUNCH(conv0_bwd_weight_kernel<0>, grid, dim3(256), 0, stream, a);
     } else {
         APTAI_LAUNCH(conv0_bwd_weight_kernel<1>, grid, dim3(256), 0, stream, a);
     }
