@@ -636,7 +636,8 @@ class GraphedForceStep:
         pool = torch.cuda.graph_pool_handle()
         # ---- encoder graph (side stream): static inputs -> enc.{ac, ids, nlen, frame_lens}
         self.g_enc = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_enc, pool=pool, stream=self._enc_stream, capture_error_mode=_CAPTURE_MODE):
+        enc_tile = int(os.environ.get("APTAI_FORCE_ENC_TILE", "128"))      # ops.auto_tile: keep whole-CU workgroups out of the side stream
+        with torch.cuda.graph(self.g_enc, pool=pool, stream=self._enc_stream, capture_error_mode=_CAPTURE_MODE), ops.auto_tile(enc_tile):
             self.enc = model._encode(self.audio, self.lengths)
         # ---- heads graph: its own copies of the encoder outputs (the next encoder replay overwrites enc.*)
         e = self.enc

@@ -143,7 +143,7 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
         d.dropout_p, d.seed = dropout_p, seed
     d.flags = flags
     d.split_k, d.accumulate = split_k, int(accumulate)
-    d.tile = tile
+    d.tile = tile if tile else _AUTO_TILE
     if tile == TILE_STREAMK:          # opt-in only: measured slower than the tile rule's choice on every hot-path shape
         ws_sk = _sk_workspace(a.device)
         d.sk_workspace, d.sk_workspace_bytes = ws_sk.data_ptr(), ws_sk.numel()
@@ -166,6 +166,29 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
             workspace = torch.empty(need, device=a.device, dtype=torch.uint8)
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     return out, workspace
+
+
+_AUTO_TILE = 0        # what `tile = 0` means to _gemm_desc: 0 = the library's rule
+
+
+class auto_tile:
+    """Context: GEMMs that leave the tile to the library run with `tile` instead (0 restores the rule).  Force_APTAI captures its side-stream
+    encoder pass under auto_tile(128): a 256 x 256 workgroup owns a whole CU (128 KiB of LDS, 2 x 240 registers per SIMD), so while such a
+    launch runs the cooperative BiLSTM workgroups of the heads cannot start beside it - the pipelined step measured 7.70 ms with 128-row
+    tiles in the encoder against 8.1-8.4 ms with the rule's 256-row launches, although the encoder alone is slower that way."""
+
+    def __init__(self, tile: int):
+        self.tile = int(tile)
+
+    def __enter__(self):
+        global _AUTO_TILE
+        self.prev, _AUTO_TILE = _AUTO_TILE, self.tile
+        return self
+
+    def __exit__(self, *exc):
+        global _AUTO_TILE
+        _AUTO_TILE = self.prev
+        return False
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, **kw) -> torch.Tensor:
