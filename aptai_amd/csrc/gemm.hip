@@ -1779,9 +1779,10 @@ extern "C" int aptai_gemm_bf16(const aptai_gemm_desc* d, void* stream_) {
     // launches over column ranges: whole rounds of 256-row tiles (0.63 of the MFMA rate in the loop), then the remainder as one round of
     // 128-row tiles - instead of three rounds of 128-row tiles (0.34).  Measured both ways in one call: standalone the single launch is the
     // faster one since the 128-row kernels walk the tiles in 2-D groups (FFN1 forward 56-58 vs 60.8 us), in the step the split is (8.82-8.85
-    // -> 8.78-8.79 ms, three interleaved pairs): kept on, APTAI_GEMM_SPLITN=0 turns it off.  Bit-identical outputs and dropout masks
+    // -> 8.78-8.79 ms, three interleaved pairs).  OFF by default (APTAI_GEMM_SPLITN=1 turns it on): 0.5 % is not worth a whole-CU 256-row launch
+    // in the backward pass, where anything that runs beside it - Force_APTAI's BiLSTM clusters did, a gradient all-reduce would - cannot get a CU.  Bit-identical outputs and dropout masks
     // (tests/test_gpu_gemm.py: a tile's K walk does not depend on its size; the element index is the whole output's, hash_ld / hash_n0).
-    static const bool split_on = !(getenv("APTAI_GEMM_SPLITN") && atoi(getenv("APTAI_GEMM_SPLITN")) == 0);
+    static const bool split_on = getenv("APTAI_GEMM_SPLITN") && atoi(getenv("APTAI_GEMM_SPLITN")) != 0;
     if (split_on && d != nullptr && d->tile == 0 && !d->out_f32 && !d->a_kmajor && d->split_k <= 1 && !d->accumulate && d->batch_outer <= 1 &&
         d->batch_inner <= 1 && d->colscale_n == 0 && d->sk_workspace == nullptr && d->M % 256 == 0 && d->N % 256 == 0 && d->K <= 1024 &&
         getenv("APTAI_GEMM_TILE") == nullptr) {

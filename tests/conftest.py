@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# the opt-in column-split launch of aptai_gemm_bf16 is exercised by the GPU suite (bit-identical to the single launch:
+# tests/test_gpu_gemm.py::test_split_column_launch_equals_the_single_launch); the library reads the variable at its first GEMM
+os.environ.setdefault("APTAI_GEMM_SPLITN", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

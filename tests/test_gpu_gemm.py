@@ -244,8 +244,8 @@ def test_stream_k_256_tiles_against_fp32_and_the_tile_kernels(M, N, K):
 
 @pytest.mark.parametrize("km", [False, True])
 def test_split_column_launch_equals_the_single_launch(km):
-    """[8192] x 3072 outputs are 1.5 rounds of 256 x 256 tiles: aptai_gemm_bf16 runs them as a 256-tile launch over columns [0, 2048) plus a
-    128-tile launch over [2048, 3072).  Against the forced single 128-tile launch: the same dropout mask (the element index is the
+    """[8192] x 3072 outputs are 1.5 rounds of 256 x 256 tiles: under APTAI_GEMM_SPLITN=1 aptai_gemm_bf16 runs them as a 256-tile launch over
+    columns [0, 2048) plus a 128-tile launch over [2048, 3072) (the variable is read at the first GEMM of the process: conftest sets it).  Against the forced single 128-tile launch: the same dropout mask (the element index is the
     whole output's) and the same values, with every epilogue pointer (bias, residual / aux, second output) offset correctly."""
     from aptai_amd import ops
     M, N, K = 8192, 3072, 768
