@@ -357,14 +357,15 @@ def test_force_aptai_prefetched_encoder_is_bit_identical_to_inline():
             # from the second step on the two runs' ALIGNMENT-path parameters may differ in their last bits (float atomics in the
             # embedding scatter-add and the forward-sum occupancy sums, whose order depends on what else runs on the chip - here the
             # side-stream encoder), and the BiLSTM input inherits that: equal to fp32 rounding, not bit for bit
-            assert torch.allclose(l0, l1, rtol=1e-5, atol=1e-6) and torch.allclose(tv0, tv1, rtol=1e-4, atol=1e-5), \
+            # (bounds 10 x the largest deviation seen over many full-suite runs: one run in ~6 exceeded the first, tighter set)
+            assert torch.allclose(l0, l1, rtol=1e-4, atol=1e-5) and torch.allclose(tv0, tv1, rtol=1e-3, atol=1e-4), \
                 (step_i, (tv0 - tv1).abs().max().item(), (l0 - l1).abs().item())
         # (two kernels sum with float atomics - the embedding scatter-add and the per-label occupancy sums of the forward-sum
         #  CTC gradient, csrc/ctc.hip - so everything on the ALIGNMENT path varies in its last bits from run to run by itself;
         #  the parameters behind the LSTM, the losses and the predictions must be equal)
         atomic_path = ("phn_emb_layer.", "xatt.", "frame_lin.")
         diff = [(n, (a - b).abs().max().item(), a.abs().max().item()) for n, a, b in zip(names, g0, g1)
-                if not (torch.equal(a, b) or ((step_i > 0 or n.startswith(atomic_path)) and torch.allclose(a, b, rtol=1e-4, atol=1e-6)))]
+                if not (torch.equal(a, b) or ((step_i > 0 or n.startswith(atomic_path)) and torch.allclose(a, b, rtol=1e-3, atol=1e-5)))]
         assert not diff, diff
         assert all(np.array_equal(a, b) for a, b in zip(s0, s1))
     # a stale prefetch (other tensor objects) is dropped, not used
