@@ -131,6 +131,8 @@ template <int FM> struct EpiWord { static constexpr int value = FM; };
     X(APTAI_EPI_BIAS | APTAI_EPI_GELU | APTAI_EPI_DROPOUT | APTAI_EPI_PRE_DGELU | EPX_PRE)   /* FFN1, training */           \
     X(APTAI_EPI_BIAS | APTAI_EPI_GELU | APTAI_EPI_PRE_DGELU | EPX_PRE)    /* FFN1, training, activation dropout 0 */        \
     X(APTAI_EPI_MUL_AUX)                                                  /* FFN2 dgrad */                                  \
+    X(APTAI_EPI_BIAS | APTAI_EPI_GELU | APTAI_EPI_DROPOUT)                /* FFN1, training, derivative not saved */        \
+    X(APTAI_EPI_DGELU | APTAI_EPI_RESIDUAL)                               /* trainable conv stack, dgrad joining a tap */   \
     X(APTAI_EPI_DGELU)
 template <class F>
 __device__ __forceinline__ void epi_dispatch(const int fx, F&& f) {
