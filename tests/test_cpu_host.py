@@ -240,3 +240,15 @@ def test_composed_frame_length_formula_equals_the_step_by_step_one():
     assert h._composed_length_constants((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)) == (-80, 320)
     t = torch.tensor([159999, 160000, 400, 399, 0], dtype=torch.int64)
     assert h.feat_extract_output_lengths(t, (10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)).tolist() == [499, 499, 1, 0, -1]
+
+
+def test_auto_tile_context_sets_and_restores_the_default_tile():
+    """ops.auto_tile: what `tile = 0` means to the GEMM descriptor builder inside the context (Force_APTAI's side-stream encoder pass)."""
+    from aptai_amd import ops
+    assert ops._AUTO_TILE == 0
+    with ops.auto_tile(128):
+        assert ops._AUTO_TILE == 128
+        with ops.auto_tile(0):
+            assert ops._AUTO_TILE == 0
+        assert ops._AUTO_TILE == 128
+    assert ops._AUTO_TILE == 0
