@@ -37,7 +37,8 @@ def test_mx_quantiser_matches_the_ocp_definition():
     assert not nz.any(), f"{int(nz.sum())} element codes differ"
 
 
-@pytest.mark.parametrize("M,N,K,gelu,res", [(256, 384, 256, False, False), (300, 768, 768, True, False), (8192, 768, 3072, False, True)])
+@pytest.mark.parametrize("M,N,K,gelu,res", [(256, 384, 256, False, False), (300, 768, 768, True, False), (8192, 768, 3072, False, True),
+                                             (70, 136, 128, False, True), (129, 8, 256, True, False)])      # one K-tile; ragged last tiles both ways
 def test_mx_gemm_equals_the_product_of_the_dequantised_operands(M, N, K, gelu, res):
     from aptai_amd import ops
     g = torch.Generator().manual_seed(1)
@@ -64,7 +65,7 @@ def test_mx_gemm_equals_the_product_of_the_dequantised_operands(M, N, K, gelu, r
         assert rel < 6e-2, rel
 
 
-@pytest.mark.parametrize("M,N,K,gelu", [(256, 384, 256, False), (300, 3072, 768, True), (3000, 4096, 1024, True)])
+@pytest.mark.parametrize("M,N,K,gelu", [(256, 384, 256, False), (300, 3072, 768, True), (3000, 4096, 1024, True), (70, 160, 128, False)])
 def test_mx_gemm_with_mx_output_is_the_gemm_followed_by_the_quantiser(M, N, K, gelu):
     """aptai_gemm_mxfp8_mxout (FFN1 -> FFN2 hand-over) against its definition: the bf16 GEMM result, quantised - every element code and
     every scale byte equal (the epilogue rounds to bf16 before it quantises; M = 300 / 3000 leave a ragged last tile)."""
