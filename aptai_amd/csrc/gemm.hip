@@ -1565,21 +1565,43 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
         read_half(0, 1);
     }
     int cur = 0;
+#ifdef APTAI_STAMPS
+    // development: shader-clock time of the K-tile's five segments, summed over the K-tiles (thread 0 of each block; slots 1, 5, 6, 7 and
+    // the high word of slot 5 hold cycles: tools/gemm256_stamps.py loop192)
+    unsigned long long seg[5] = {0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime();
+#define SEG(i) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); seg[i] += tn - tp; tp = tn; } while (0)
+#else
+#define SEG(i) do {} while (0)
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         const int nxt = cur == 2 ? 0 : cur + 1;
         mfma_half(0);
+        SEG(0);
         if (kt + 1 < nk) {
             if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            SEG(1);
             if (kt + 3 < nk) stage(cur);
             read_half(nxt, 0);
+            SEG(2);
         }
         mfma_half(1);
+        SEG(3);
         if (kt + 1 < nk) read_half(nxt, 1);
+        SEG(4);
         cur = nxt;
     }
+#ifdef APTAI_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0 && blockIdx.z == 0) {
+        g_stamps[blockIdx.x * 8 + 1] = seg[0];
+        g_stamps[blockIdx.x * 8 + 5] = seg[1];
+        g_stamps[blockIdx.x * 8 + 6] = seg[2];
+        g_stamps[blockIdx.x * 8 + 7] = seg[3] | (seg[4] << 32);
+    }
+#endif
+#undef SEG
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();

@@ -60,6 +60,30 @@ def run(M, N, K, lda=None, gelu=False, tile=256, km=False, heavy=False):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "loop192":
+        # shader-clock cycles of the five segments of the 192-row kernel's K-tile (K-contiguous operands), per K-tile, thread 0 of each block
+        for (n, k) in ((768, 768), (768, 3072), (2304, 768)):
+            M = 8192
+            g = torch.Generator(device="cuda").manual_seed(0)
+            a = torch.randn(M, k, device="cuda", generator=g).to(torch.bfloat16)
+            w = torch.randn(n, k, device="cuda", generator=g).to(torch.bfloat16)
+            for _ in range(3):
+                ops.gemm(a, w, M, n, k, tile=192)
+            torch.cuda.synchronize()
+            buf = np.zeros(4096 * 8, dtype=np.uint64)
+            lib = _lib.lib()
+            lib.aptai_debug_read_stamps.argtypes = [ctypes.c_void_p]
+            lib.aptai_debug_read_stamps.restype = ctypes.c_int
+            assert lib.aptai_debug_read_stamps(buf.ctypes.data) == 0
+            nb = (M // 128) * (n // 192)
+            st = buf.reshape(4096, 8)[:nb]
+            nk = k // 64
+            seg = np.stack([st[:, 1], st[:, 5], st[:, 6], st[:, 7] & np.uint64(0xffffffff), st[:, 7] >> np.uint64(32)], 1).astype(np.float64) / nk
+            names = ["MFMA half 0 (issue)", "wait + barrier", "DMA issue + reads half 0", "MFMA half 1 (issue)", "reads half 1 (issue)"]
+            print(f"== 192-row tile NT {M} x {n} x {k}: cycles per K-tile (mean over {nb} blocks), total {seg.sum(1).mean():.0f}")
+            for i, nm in enumerate(names):
+                print(f"   {nm:26s} {seg[:, i].mean():7.0f}")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         for tile in (128, 192, 64):
             run(8192, 768, 768, tile=tile)
