@@ -9,7 +9,7 @@
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-template <int MODE, int THREADS>
+template <int MODE, int THREADS, int STRIDE_BYTES = 0>
 __global__ __launch_bounds__(THREADS) void stream_kernel(const char* __restrict__ src, long window, int niter, unsigned* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6;
@@ -19,7 +19,15 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const char* __restrict_
     unsigned acc = 0;
     for (int it = 0; it < niter; ++it) {
         char* buf = smem + (it & 1) * STAGE;
-        if (MODE == 0) {
+        if (MODE == 2) {
+            // a GEMM operand tile: thread t fetches 16 B of row (k * THREADS + t) >> 3 at row stride `window_stride` (passed in niter's upper bits)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cid = k * THREADS + tid, row = cid >> 3, ch = cid & 7;
+                const char* p = src + off + (long)row * STRIDE_BYTES + ch * 16;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(buf + k * THREADS * 16 + wave * 1024), 16, 0, 0);
+            }
+        } else if (MODE == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const char* p = src + off + (long)k * THREADS * 16 + tid * 16;
@@ -32,8 +40,8 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const char* __restrict_
 #pragma unroll
             for (int k = 0; k < 4; ++k) *(u32x4*)(buf + k * THREADS * 16 + tid * 16) = v[k];
         }
-        off += STAGE;
-        if (off + STAGE > window) off = 0;
+        off += MODE == 2 ? 128 : STAGE;                     // strided mode: the next K-tile = the next 128 bytes of every row
+        if (MODE == 2 ? (off % STRIDE_BYTES) + 128 > STRIDE_BYTES || off + (long)(THREADS / 2) * STRIDE_BYTES + 128 > window : off + STAGE > window) off = ((long)blockIdx.x * 65536) % (window / 4);
         if ((it & 7) == 7) {                                   // touch the data now and then so nothing is optimised away
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();
@@ -44,7 +52,7 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const char* __restrict_
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
-template <int MODE, int THREADS>
+template <int MODE, int THREADS, int STRIDE_BYTES = 0>
 void run(const char* name, const char* d, long window, int blocks_per_cu, unsigned* sink) {
     const int niter = 4096, ncu = 256;
     const int smem = 2 * THREADS * 64;
@@ -52,7 +60,7 @@ void run(const char* name, const char* d, long window, int blocks_per_cu, unsign
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((stream_kernel<MODE, THREADS>), dim3(ncu * blocks_per_cu), dim3(THREADS), smem, 0, d, window, niter, sink);
+        hipLaunchKernelGGL((stream_kernel<MODE, THREADS, STRIDE_BYTES>), dim3(ncu * blocks_per_cu), dim3(THREADS), smem, 0, d, window, niter, sink);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
     }
@@ -66,6 +74,11 @@ int main() {
     char* d; unsigned* sink;
     const long total = 64L << 20;
     hipMalloc(&d, total); hipMemset(d, 1, total); hipMalloc(&sink, 4);
+    // GEMM-like strided tiles out of a 6 MiB window (rows of 1536 / 6144 bytes: K = 768 / 3072 bf16): 4 x THREADS / 8 rows x 128 B per stage
+    run<2, 512, 1536>("LDS-DMA, rows @ 1536 B", d, 6L << 20, 1, sink);
+    run<2, 512, 6144>("LDS-DMA, rows @ 6144 B", d, 6L << 20, 1, sink);
+    run<2, 256, 1536>("LDS-DMA, rows @ 1536 B", d, 6L << 20, 2, sink);
+    run<0, 512>("LDS-DMA contiguous", d, 6L << 20, 1, sink);
     for (long window : {2L << 20, 32L << 20}) {
         run<0, 256>("LDS-DMA", d, window, 1, sink);
         run<0, 256>("LDS-DMA", d, window, 2, sink);
