@@ -24,7 +24,18 @@ struct Conv0Args {
     float* partials;       // [B][nchunks][2][512]
     const float* stats;    // [B][2][512]  (mean, rstd)
     int nchunks;
+    const int* bounds;     // bucketed hipGraphs (runtime.hip, aptai_set_frame_bounds): bounds[0] = frames of the batch AS COLLATED, or null
 };
+
+// Frames that exist in the batch as the reference collated it.  A graph captured for a bucket length sees T_real = the bucket's frames;
+// the window of frame T_batch still covers 5..9 real samples of an utterance that fills the batch (it starts at sample 5 T_batch <
+// S_batch), but that frame exists neither in the reference nor in the eager run: it must enter neither the GroupNorm statistics nor the
+// weight gradients (round-3 advice: the static-length sums were off by that one frame, ~1/T0 relative).
+__device__ __forceinline__ int frames_collated(const int* __restrict__ bounds, int T_real) {
+    if (bounds == nullptr) return T_real;
+    const int tb = bounds[0];
+    return tb < 1 ? 1 : (tb < T_real ? tb : T_real);
+}
 
 __device__ __forceinline__ void load_weights(const Conv0Args& a, int lane, float (&w)[8][KW], float (&bias)[8]) {
 #pragma unroll
@@ -118,8 +129,9 @@ __global__ __launch_bounds__(256) void conv0_layer_kernel(Conv0Args a) {
 constexpr int AC_TERMS = KW + KW * (KW + 1) / 2;        // 65
 constexpr int AC_FRAMES_PER_BLOCK = 1024;
 
-__global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ audio, long S, int T_real,
-                                                            float* __restrict__ partials, int nch) {
+__global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ audio, long S, int T_static,
+                                                            float* __restrict__ partials, int nch, const int* __restrict__ bounds) {
+    const int T_real = frames_collated(bounds, T_static);
     __shared__ float red[4][AC_TERMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -162,11 +174,8 @@ __global__ void conv0_moments_final_kernel(const float* __restrict__ partials, c
     if (c < AC_TERMS) {
         double s = 0.0;
         for (int k = 0; k < nch; ++k) s += (double)partials[((long)b * nch + k) * AC_TERMS + c];
-        // bucketed hipGraphs: the waveform beyond the batch's own padded length is zero, so the sums are those of the batch as
-        // collated; only the frame COUNT of the statistics follows the bound (runtime.hip, aptai_set_frame_bounds)
-        int tdiv = T_real;
-        if (bounds != nullptr) { const int tb = bounds[0]; tdiv = tb < 1 ? 1 : (tb < T_real ? tb : T_real); }
-        mom[c] = s / tdiv;
+        // bucketed hipGraphs: sums (conv0_moments_kernel) and frame count both follow the batch as collated
+        mom[c] = s / frames_collated(bounds, T_real);
     }
     __syncthreads();
     double wk[KW];
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_group_stats_kernel(Conv0BwdArgs
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
     const int t0 = chunk * BWD_FRAMES_PER_BLOCK;
     int t1 = t0 + BWD_FRAMES_PER_BLOCK;
-    t1 = t1 < f.T_real ? t1 : f.T_real;
+    { const int te = frames_collated(f.bounds, f.T_real); t1 = t1 < te ? t1 : te; }
     for (int t = t0 + wave; t < t1; t += 4) {
         float v[8], d[8];
         conv_frame(xb + (long)t * STRIDE, w, bias, v);
@@ -404,8 +413,7 @@ __global__ __launch_bounds__(1024) void conv0_bwd_group_final_kernel(const float
                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
                                                                      int nchunks, int T_real_static, const int* __restrict__ bounds) {
     __shared__ double red[2][16][64];
-    int T_real = T_real_static;
-    if (bounds != nullptr) { const int tb = bounds[0]; T_real = tb < 1 ? 1 : (tb < T_real_static ? tb : T_real_static); }
+    const int T_real = frames_collated(bounds, T_real_static);
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double tg = 0.0, tb = 0.0;
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_kernel(Conv0BwdArgs a) {
         for (int k = 0; k < 13; ++k) acc[j][k] = 0.f;
     const int t0 = chunk * BWD_FRAMES_PER_BLOCK;
     int t1 = t0 + BWD_FRAMES_PER_BLOCK;
-    t1 = t1 < f.T_real ? t1 : f.T_real;
+    { const int te = frames_collated(f.bounds, f.T_real); t1 = t1 < te ? t1 : te; }
     for (int t = t0 + wave; t < t1; t += 4) {
         float v[8], d[8], du[8], smp[KW];
         const float* xs = xb + (long)t * STRIDE;
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_group_stats_mfma_kernel(Conv0Bw
     const long last = f.S - 1;
     const int tb = chunk * BWD_FRAMES_PER_BLOCK;
     int t1 = tb + BWD_FRAMES_PER_BLOCK;
-    t1 = t1 < f.T_real ? t1 : f.T_real;
+    { const int te = frames_collated(f.bounds, f.T_real); t1 = t1 < te ? t1 : te; }
     for (int t0 = tb; t0 < t1; t0 += 16) {
         float x1[3];
 #pragma unroll
@@ -631,7 +639,7 @@ __global__ __launch_bounds__(256) void conv0_bwd_weight_mfma_kernel(Conv0BwdArgs
     for (int g = 0; g < 8; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tb = chunk * BWD_FRAMES_PER_BLOCK;
     int t1 = tb + BWD_FRAMES_PER_BLOCK;
-    t1 = t1 < f.T_real ? t1 : f.T_real;
+    { const int te = frames_collated(f.bounds, f.T_real); t1 = t1 < te ? t1 : te; }
     for (int t0 = tb; t0 < t1; t0 += 16) {
         // operands of both contractions from the waveform (L1-resident: 16 frames = 85 samples); a software prefetch of the next block's
         // operands measured 4 % slower (645 -> 674 us for the whole call): the waves of a SIMD already cover each other's loads
@@ -743,7 +751,7 @@ extern "C" int aptai_conv0_fwd(const float* audio, int64_t B, int64_t S, const f
     a.stats = stats;
     const int nch = (int)ceil_div(T_real, AC_FRAMES_PER_BLOCK);   // [B][nch][65] floats: fits the conv-pass workspace
     APTAI_LAUNCH(conv0_moments_kernel, dim3((unsigned)nch, (unsigned)B), dim3(256), 0, stream, audio, (long)S, (int)T_real,
-                 a.partials, nch);
+                 a.partials, nch, (const int*)aptai_frame_bounds(stream_));
     APTAI_CHECK_LAUNCH("conv0_moments_kernel");
     APTAI_LAUNCH(conv0_moments_final_kernel, dim3((unsigned)B), dim3(C0), 0, stream, (const float*)a.partials, weight, bias,
                  stats, nch, (int)T_real, eps, (const int*)aptai_frame_bounds(stream_));
@@ -789,6 +797,7 @@ extern "C" int aptai_conv0_bwd(const float* audio, int64_t B, int64_t S, const f
     a.f.audio = audio; a.f.S = S; a.f.w = weight; a.f.bias = bias; a.f.gamma = gamma; a.f.beta = beta; a.f.B = (int)B;
     a.f.T_real = (int)T_real; a.f.T_alloc = (int)T_alloc; a.f.eps = eps; a.f.stats = fwd_stats;
     a.f.nchunks = (int)ceil_div(T_real, BWD_FRAMES_PER_BLOCK);
+    a.f.bounds = mode == 0 ? (const int*)aptai_frame_bounds(stream_) : nullptr;
     a.dy = (const bf16_t*)dy;
     float* ws = (float*)workspace;
     a.gpart = ws;

@@ -210,15 +210,22 @@ __global__ void ctc_reduce_kernel(const float* __restrict__ nll, const int* __re
 }
 
 // ---- 3. gradient rows:  scale_b * (softmax - occupancy).  One wave per row (b, t) of the [B][rows_per_b] output.
+// The occupancy of a label is a sum over the states that carry it.  Round 3 scattered exp(.) into LDS with float atomicAdd: the order
+// of those additions is not defined, so the last bits of the gradient changed from launch to launch (and Adam's sign-like first steps
+// turned that into O(lr) parameter differences: the graph-vs-eager loop test of round 3).  Now ORDER-FIXED: every state's occupancy is
+// written to its own LDS word; the blank's sum runs per lane over its (even) states in increasing order and then through the fixed
+// shuffle tree; the lane that owns vocabulary entry v adds the states of the labels equal to v in label order.  Same inputs -> same bits.
+constexpr int CTC_MAXS = 512;                                     // 2 * 255 + 1 states at most (checked in fill())
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcArgs a, const float* __restrict__ lpe, const float* __restrict__ beta,
                                                        const float* __restrict__ grad_out, int reduction, int zero_infinity,
                                                        void* __restrict__ dlogits, long ldd, float extra_scale) {
-    __shared__ float occs[4][MAXV];
+    __shared__ float ev[4][CTC_MAXS];                             // occupancy of state s
+    __shared__ int lab[4][CTC_MAXS / 2];                          // label of odd state 2 i + 1
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long f = (long)blockIdx.x * 4 + wave;
-    if (f >= (long)a.B * a.rows_per_b) return;
-    const int b = (int)(f / a.rows_per_b), t = (int)(f % a.rows_per_b);
+    const bool valid = f < (long)a.B * a.rows_per_b;              // every thread reaches the barrier below
+    const int b = valid ? (int)(f / a.rows_per_b) : 0, t = valid ? (int)(f % a.rows_per_b) : 0;
     int Tb = a.input_lens[b];
     Tb = Tb < a.T ? Tb : a.T;
     const int L = a.target_lens[b], S = 2 * L + 1;
@@ -228,18 +235,21 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcArgs a, const float* _
     if (reduction == 1) scale /= (float)((L < 1 ? 1 : L)) * (float)a.B;
     const bool dead = isinf(nll) || isnan(nll);                  // infeasible alignment: zero_infinity -> zero gradient
     if (dead && zero_infinity) scale = 0.f;
-    const bool active = t < Tb && !dead;
+    const bool active = valid && t < Tb && !dead;
     const long r = (long)b * a.rows_per_b + t;
-    float* occ = occs[wave];
+    float blank_part = 0.f;
     if (active) {
-        for (int v = lane; v < MAXV; v += 64) occ[v] = 0.f;
         const long off = ((long)b * a.T + t) * a.S_max;
-        for (int s = lane; s < S; s += 64) {
-            const int e = (s & 1) ? a.targets[(long)b * a.ldt + (s >> 1)] : a.blank;
+        for (int s = lane; s < S; s += 64) {                     // s and lane have the same parity: even lanes own the blank states
             const float lg = a.alpha[off + s] + beta[off + s] - lpe[off + s] + nll;        // log occupancy, <= 0
-            if (lg > -80.f && e >= 0 && e < MAXV) atomicAdd(&occ[e], __expf(lg));
+            const float o = lg > -80.f ? __expf(lg) : 0.f;
+            ev[wave][s] = o;
+            if (s & 1) lab[wave][s >> 1] = a.targets[(long)b * a.ldt + (s >> 1)];
+            else blank_part += o;
         }
     }
+    const float blank_occ = wave_sum(blank_part);                // fixed shuffle tree
+    __syncthreads();
     // softmax of the row (recomputed: V <= 256 values)
     const float* row = a.logits + r * a.ldl;
     float x[MAXV / 64];
@@ -256,12 +266,19 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(CtcArgs a, const float* _
     for (int j = 0; j < MAXV / 64; ++j) se += (active && j * 64 + lane < Vb) ? __expf(x[j] - mx) : 0.f;
     se = wave_sum(se);
     const float inv = active ? 1.f / se : 0.f;
+    if (!valid) return;
 #pragma unroll
     for (int j = 0; j < MAXV / 64; ++j) {
         const int v = j * 64 + lane;
+        if (j * 64 >= (int)ldd) break;                           // wave-uniform
+        float occ = 0.f;
+        if (active && j * 64 < a.V) {
+            occ = v == a.blank ? blank_occ : 0.f;
+            for (int i = 0; i < L; ++i) occ += lab[wave][i] == v ? ev[wave][2 * i + 1] : 0.f;   // LDS broadcasts, label order
+        }
         if (v >= (int)ldd) continue;
         float gv = 0.f;
-        if (active && v < Vb) gv = scale * (__expf(x[j] - mx) * inv - occ[v]);
+        if (active && v < Vb) gv = scale * (__expf(x[j] - mx) * inv - occ);
         if (OUT_BF16) ((bf16_t*)dlogits)[r * ldd + v] = f2bf(gv);
         else ((float*)dlogits)[r * ldd + v] = gv;
     }

@@ -220,16 +220,36 @@ __global__ void embed_pe_fwd_kernel(const int* __restrict__ ids, const float* __
         out[i] = v;
     }
 }
-__global__ void embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dout, float* __restrict__ demb, int rows,
-                                 int D, float scale_keep, uint32_t s0, uint32_t s1, uint32_t thr) {
-    const long n = (long)rows * D;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int r = (int)(i / D), d = (int)(i % D);
-        const int id = ids[r];
-        if (id == 0) continue;                                      // padding_idx = 0 receives no gradient
-        float v = dout[i];
-        if (thr) v = drop_keep((uint64_t)i, s0, s1, thr) ? v * scale_keep : 0.f;
-        atomicAdd(&demb[(long)id * D + d], v);
+// ORDER-FIXED (round 4; was one float atomicAdd per element: the sum over the rows that share a phoneme id had no defined order, so
+// phn_emb_layer.weight.grad changed in its last bits from launch to launch).  One block per row; the block of the FIRST row that
+// carries an id owns that id's gradient row and adds the later rows with the same id in row order; other blocks leave at once.
+__global__ __launch_bounds__(128) void embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dout, float* __restrict__ demb,
+                                                        int rows, int D, float scale_keep, uint32_t s0, uint32_t s1, uint32_t thr) {
+    __shared__ int sid[1024];
+    const int r0 = blockIdx.x;
+    const int id = ids[r0];
+    if (id == 0) return;                                            // padding_idx = 0 receives no gradient (block-uniform)
+    int dup = 0;
+    for (int i = threadIdx.x; i < r0; i += blockDim.x) dup |= ids[i] == id;
+    if (__syncthreads_or(dup)) return;
+    for (int d0 = 0; d0 < D; d0 += blockDim.x) {
+        const int d = d0 + threadIdx.x;
+        float acc = 0.f;
+        for (int base = r0; base < rows; base += 1024) {
+            const int n = rows - base < 1024 ? rows - base : 1024;
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += blockDim.x) sid[i] = ids[base + i];
+            __syncthreads();
+            if (d < D)
+                for (int i = 0; i < n; ++i) {
+                    if (sid[i] != id) continue;                     // block-uniform
+                    const long e = (long)(base + i) * D + d;
+                    float v = dout[e];
+                    if (thr) v = drop_keep((uint64_t)e, s0, s1, thr) ? v * scale_keep : 0.f;
+                    acc += v;
+                }
+        }
+        if (d < D) demb[(long)id * D + d] = acc;
     }
 }
 
@@ -574,7 +594,7 @@ extern "C" int aptai_embed_bwd(const int32_t* ids, const float* dout, float* dem
                                uint64_t seed, void* stream) {
     APTAI_REQUIRE(ids && dout && demb_zeroed && rows > 0, "aptai_embed_bwd: bad arguments");
     const uint32_t thr = drop_thr16(dropout_p);
-    APTAI_LAUNCH(embed_bwd_kernel, dim3(gridn(rows * D)), dim3(256), 0, (hipStream_t)stream, ids, dout, demb_zeroed, (int)rows, (int)D,
+    APTAI_LAUNCH(embed_bwd_kernel, dim3((unsigned)rows), dim3(128), 0, (hipStream_t)stream, ids, dout, demb_zeroed, (int)rows, (int)D,
                  drop_scale(thr), (uint32_t)seed, (uint32_t)(seed >> 32), thr);
     APTAI_CHECK_LAUNCH("embed_bwd_kernel");
     return APTAI_OK;

@@ -33,3 +33,50 @@ def test_conv0_backward_group_mode_against_fp64_autograd(B, S, ragged):
     for name, got, ref in (("dweight", dw, wd.grad), ("dgamma", dg, gd.grad), ("dbeta", db, bd.grad)):
         err = (got.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
         assert err < 2e-5, (name, err)                      # measured 2-4e-7: fp32 sums of ~3 000 frames per channel
+
+
+@pytest.mark.parametrize("S,Sb", [(19200, 32000), (23337, 24000)])
+def test_conv0_group_statistics_follow_the_collated_batch_inside_a_bucket(S, Sb):
+    """Bucketed hipGraphs (graphed.BucketedGraphedStep) run the first conv layer on a waveform zero-padded from the batch's own length S
+    to a bucket Sb with per-step frame bounds (aptai_set_frame_bounds).  Frame T(S) of the padded waveform starts at sample 5 T(S) < S,
+    so its window still covers 5..9 REAL samples of an utterance that fills the batch - a frame the reference (GroupNorm over the frames of
+    the batch as collated, HF:317-323) does not have.  Round 3 summed the window moments and the backward's sums over the bucket's frames
+    (advice r3, conv.hip:133): statistics and gradients must be BIT-IDENTICAL to the un-bucketed shape, with nonzero samples in the tail."""
+    from aptai_amd import graphed, ops
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    audio = torch.randn(B, S, generator=g)                 # nonzero up to the very last sample
+    w = torch.randn(512, 1, 10, generator=g) * 0.3
+    gamma = 1.0 + 0.1 * torch.randn(512, generator=g)
+    beta = 0.1 * torch.randn(512, generator=g)
+    T, Tb = (S - 10) // 5 + 1, (Sb - 10) // 5 + 1
+    assert 5 * T < S                                        # the frame that must not be counted does see real samples
+    Ta, Tba = (T + 63) // 64 * 64, (Tb + 63) // 64 * 64
+    dy = (torch.randn(B, Ta, 512, generator=g) * 0.5).to(torch.bfloat16)
+    dy[:, T:] = 0
+    dyb = torch.zeros(B, Tba, 512, dtype=torch.bfloat16)
+    dyb[:, :Ta] = dy
+    dev = "cuda"
+    P = [t.to(dev) for t in (w, gamma, beta)]
+    out = torch.empty(B, Ta, 512, device=dev, dtype=torch.bfloat16)
+    stats = ops.conv0_fwd(audio.to(dev), P[0], None, P[1], P[2], 0, out, T, Ta, want_stats=True)
+    ref = ops.conv0_bwd(audio.to(dev), P[0], None, P[1], P[2], 0, dy.to(dev), T, Ta, stats)
+    audio_b = torch.nn.functional.pad(audio, (0, Sb - S)).to(dev)
+    outb = torch.empty(B, Tba, 512, device=dev, dtype=torch.bfloat16)
+    stream = torch.cuda.current_stream().cuda_stream
+    bounds = torch.tensor([T, 1], device=dev, dtype=torch.int32)
+    graphed._bind_bounds(stream, bounds)
+    try:
+        stats_b = ops.conv0_fwd(audio_b, P[0], None, P[1], P[2], 0, outb, Tb, Tba, want_stats=True)
+        got = ops.conv0_bwd(audio_b, P[0], None, P[1], P[2], 0, dyb.to(dev), Tb, Tba, stats_b)
+        torch.cuda.synchronize()
+    finally:
+        graphed._unbind_salt(stream)
+    assert torch.equal(stats, stats_b)
+    assert torch.equal(out[:, :T], outb[:, :T])
+    for name, a, b in zip(("dweight", "dbias", "dgamma", "dbeta"), ref, got):
+        if a is not None:
+            assert torch.equal(a, b), (name, (a - b).abs().max().item())
+    # and without the bounds the bucket's statistics are NOT the batch's (the test has teeth)
+    stats_n = ops.conv0_fwd(audio_b, P[0], None, P[1], P[2], 0, outb, Tb, Tba, want_stats=True)
+    assert not torch.equal(stats, stats_n)

@@ -158,7 +158,15 @@ def test_device_best_path_decode_matches_the_host_definition():
 def test_phoneme_recognizer_loop_replays_graphs_on_the_reference_collate(tmp_path):
     """train_phoneme_recognizer.train with cfg.graphed: the reference's collate (per-batch padding of waveforms and label lists,
     train/train_phoneme_recognizer.py:224-239) feeds BucketedGraphedStep; the trainable conv stack, CTC head and optimiser run as
-    replayed segments.  With the regularisers off the epoch's losses equal the eager loop's from the same initial state."""
+    replayed segments.  With the regularisers off the epoch's losses equal the eager loop's from the same initial state.
+
+    Round 3 this test was RED (step-8 losses 6.7262 vs 6.763).  Cause, established in round 4 by A/B builds (tools/pr_loop_ab.py,
+    profiles/r04_pr_loop_cause.txt): the bucketed graphs summed the first conv layer's GroupNorm moments over the BUCKET's frames, and frame
+    T(S) of the zero-padded waveform still covers 5..9 real samples - one frame the reference does not have, ~1/T0 relative in the
+    statistics, amplified by Adam over 8 steps.  (The CTC gradient's float atomics were NOT it; they are order-fixed now all the same.)
+    With the sums clamped to the collated frame count the step-1 gradients of every parameter are bit-identical to the eager step's
+    (tools/pr_graph_vs_eager.py, profiles/r04_pr_graph_vs_eager_step1.txt) and the two 8-step traces agree in every printed digit, so
+    the bound is the print resolution, not a trajectory tolerance."""
     from aptai_amd import hostlogic, train_phoneme_recognizer as T
     from aptai_amd.config import W2V2Config
     from aptai_amd.wav2vec2 import Wav2Vec2Model
@@ -184,7 +192,8 @@ def test_phoneme_recognizer_loop_replays_graphs_on_the_reference_collate(tmp_pat
         logs[graphed] = ([float(l.split("train_loss:")[1]) for l in lines if l.startswith("\tepoch")], hist)
     le, lg = logs[False][0], logs[True][0]
     assert len(le) == len(lg) == 8
+    print(f"[bands] PR loop graph vs eager: largest relative loss deviation over 8 steps {max(abs(a - b) / abs(a) for a, b in zip(le, lg)):.2e}")
     for a, b in zip(le, lg):
-        assert abs(a - b) <= 5e-3 * abs(a), (le, lg)
+        assert abs(a - b) <= 1.5e-4 + 1e-5 * abs(a), (le, lg)              # losses are logged with 4 decimals
     for he, hg in zip(logs[False][1], logs[True][1]):
-        assert abs(he["mean_val_loss"] - hg["mean_val_loss"]) <= 5e-3 * abs(he["mean_val_loss"])
+        assert abs(he["mean_val_loss"] - hg["mean_val_loss"]) <= 1e-4 * abs(he["mean_val_loss"])
