@@ -322,3 +322,53 @@ def test_bucketed_graphs_equal_the_eager_loop_on_variable_length_batches():
             assert (tv0[u, :n] - tv1[u, :n]).abs().max().item() <= 2e-2 * tv0[u, :n].abs().max().item(), (i, u)
             assert (p0[u, :n] != p1[u, :n]).float().mean().item() <= 0.1, (i, u)       # near-uniform random-init logits: a few bf16 near-ties flip once the two runs' parameters differ in their last bits (4 of 99 frames measured)
     assert rec["eager"][-1][0] < rec["eager"][0][0] * 1.5
+
+
+def test_bucketed_pr_step_gradients_equal_the_eager_step_from_identical_parameters():
+    """What a loss-after-N-Adam-steps comparison cannot separate (round-3 verdict, item 1a): the gradients of EVERY parameter after one
+    backward, graph replay inside a bucket vs the eager step on the batch as collated, from identical parameters (optimiser at lr 0).
+    Bucket with the same padded frame count (1.2 s -> 2 s: Tp = 128 both): the same kernels on the same rows -> bit-identical.
+    Bucket with another padded frame count (-> 3 s: Tp = 256, other split-K / tile choices): equal to summation order, rel-L2 <= 2e-3."""
+    from aptai_amd import hostlogic, train_phoneme_recognizer as T
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.graphed import BucketedGraphedStep
+    from aptai_amd.optim import Adam
+    from oracle import synth
+    from test_gpu_ctc_pr import _build_pr
+    cfg = W2V2Config.base(num_hidden_layers=2, hidden_dropout=0., activation_dropout=0., attention_dropout=0., feat_proj_dropout=0.,
+                          final_dropout=0., layerdrop=0., apply_spec_augment=False, vocab_size=40, ctc_loss_reduction="mean",
+                          ctc_zero_infinity=True)
+    sd = synth.make_state_dict(synth.pr_param_shapes(cfg), 0)
+    ds = T.SyntheticCommonPhone(4, 1.2, 40, seed=1)
+    batches = [{k: v.cuda() for k, v in hostlogic.collate_pr([ds[2 * i], ds[2 * i + 1]]).items()} for i in range(2)]
+    assert batches[0]["input_values"].shape[1] == 19200            # an utterance fills the batch: frame T(S) sees real samples
+    model = _build_pr(cfg, sd)
+    model.train()
+    ref = []
+    for b in batches:
+        model.zero_grad(set_to_none=True)
+        out = model(**b)
+        out["loss"].backward()
+        ref.append((out["loss"].detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    for buckets, exact in (([32000], True), ([48000], False)):
+        model.zero_grad(set_to_none=True)
+        opt = Adam([p for p in model.parameters() if p.requires_grad], lr=0.0).publish_to(model)
+        worst = 0.0
+        with BucketedGraphedStep(model, opt, bucket_samples=buckets) as runner:
+            for b, (loss, grads) in zip(batches, ref):
+                out = runner.step(b)
+                assert abs(out["loss"].item() - loss.item()) <= (0 if exact else 1e-4 * abs(loss.item()))
+                assert len(grads) > 40
+                for n, p in model.named_parameters():
+                    if n not in grads:
+                        continue
+                    if exact:
+                        assert torch.equal(p.grad, grads[n]), (buckets, n, (p.grad - grads[n]).abs().max().item())
+                    else:
+                        rel = ((p.grad.double() - grads[n].double()).norm() / (grads[n].double().norm() + 1e-30)).item()
+                        worst = max(worst, rel)
+                        assert rel <= 2e-3, (buckets, n, rel)
+        model.wav2vec2._cache_mode = None
+        model.wav2vec2._cache.clear()
+        if not exact:
+            print(f"[bands] bucketed PR step vs eager, other padded frame count: worst per-parameter gradient rel-L2 {worst:.2e}")
