@@ -87,7 +87,7 @@ typedef struct {
     int64_t batch_stride_a[2], batch_stride_b[2], batch_stride_c[2], batch_stride_bias[2], batch_stride_res[2],
         batch_stride_aux[2];
     int tile;                       /* 0 = auto, 64 = 64x128 tile (3 blocks/CU, K-contiguous A), 128 = 128x128 tile kernel (2 blocks/CU), 192 = 128x192 tile, 3-stage ring
-                                       (1 block/CU), 256 = 256x256 deep-pipelined kernel, 257 = the same tile as a persistent stream-K
+                                       (1 block/CU), 256 = 256x256 deep-pipelined kernel, 448 = 256x192 tile (bf16 out, K-contiguous A, one problem), 257 = the 256x256 tile as a persistent stream-K
                                        kernel (one workgroup per CU, equal shares of (tile, K-tile) iterations; needs sk_workspace) */
     int colscale_n; float colscale; /* bf16 output: columns [0, colscale_n) *= colscale after alpha / bias (colscale_n % 8 == 0).  The fused
                                        q|k|v projection (HF:495-498) hands the attention kernels Q already multiplied by

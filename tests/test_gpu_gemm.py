@@ -38,11 +38,14 @@ class _TileOps:
         tile = self._tile
         if tile == 257 and (a[2] < 256 or a[3] < 256 or kw.get("batch") is not None or kw.get("split_k", 1) > 1 or kw.get("accumulate")):
             tile = 0                                   # the stream-K form takes un-batched, un-split problems of >= one 256 x 256 tile
+        if tile == 448 and (kw.get("a_kmajor") or kw.get("out_f32") or kw.get("batch") is not None or kw.get("split_k", 1) > 1
+                            or kw.get("accumulate") or kw.get("residual_f32") is not None):
+            tile = 0                                   # the 256 x 192 kernel: bf16 output, K-contiguous A, one un-batched un-split problem
         kw.setdefault("tile", tile)
         return self._ops.gemm(*a, **kw)
 
 
-@pytest.fixture(scope="module", params=[0, 64, 128, 192, 256, 257], ids=["auto", "t64", "t128", "t192", "t256", "streamk"])
+@pytest.fixture(scope="module", params=[0, 64, 128, 192, 256, 257, 448], ids=["auto", "t64", "t128", "t192", "t256", "streamk", "t256x192"])
 def ops(request):
     from aptai_amd import ops
     return _TileOps(ops, request.param)
@@ -269,3 +272,35 @@ def test_split_column_launch_equals_the_single_launch(km):
     assert torch.equal((one == 0), (two == 0)) and 0.08 < (two == 0).float().mean().item() < 0.13
     assert torch.equal(one.view(torch.int16), two.view(torch.int16))
     assert torch.equal(pre1.view(torch.int16), pre2.view(torch.int16))
+
+
+@pytest.mark.parametrize("km", [False, True], ids=["nt", "nn"])
+@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (4096, 3072, 1024), (1000, 2304, 128), (300, 200, 64)])
+def test_256x192_tile_equals_the_128_tile_bit_for_bit(M, N, K, km):
+    """tile = 448 (csrc/gemm_t4.hip: 256 x 192 x 64, A double- / B triple-buffered, two wave groups one barrier apart).  A tile's K walk
+    does not depend on its size (same 32-deep MFMA chain per output element), so plain and heavy-epilogue results - dropout masks and
+    second outputs included - must EQUAL the 128-row kernel's, at whole-round shapes, ragged edges and a single K-tile; repeated launches
+    must repeat (a hazard in the staging schedule would not)."""
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _rand((M, K), g).cuda()
+    b = (_rand((K, N), g, 0.1) if km else _rand((N, K), g, 0.1)).cuda()
+    kw = dict(b_kmajor=True) if km else {}
+    ref = ops.gemm(a, b, M, N, K, tile=128, **kw)
+    _cmp(ref, a.float().cpu() @ (b.float().cpu() if km else b.float().cpu().t()))
+    for _ in range(3):
+        assert torch.equal(ops.gemm(a, b, M, N, K, tile=448, **kw), ref)
+    bias = torch.randn(N, generator=g).cuda()
+    res, aux = _rand((M, N), g).cuda(), _rand((M, N), g).cuda()
+    p1, p2 = (torch.empty(M, N, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+    heavy = [dict(bias=bias, gelu=True, out_pre=p1, pre_dgelu=True, dropout_p=0.1, seed=77), dict(bias=bias, residual=res, dropout_p=0.1, seed=78),
+             dict(mul_aux=aux), dict(dgelu_aux=aux, residual=res), dict(bias=bias, colscale=(N // 8 * 8 // 2 // 8 * 8, 0.18))]
+    for h in heavy:
+        h2 = dict(h)
+        if "out_pre" in h2:
+            h2["out_pre"] = p2
+        o1 = ops.gemm(a, b, M, N, K, tile=128, **kw, **h)
+        o2 = ops.gemm(a, b, M, N, K, tile=448, **kw, **h2)
+        assert torch.equal(o1, o2), (sorted(h), (o1.float() - o2.float()).abs().max().item())
+        if "out_pre" in h:
+            assert torch.equal(p1, p2)
