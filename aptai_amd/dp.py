@@ -240,6 +240,10 @@ class GradBucketReducer:
             self._launch(bi)
         self.finish()
 
+    def plan_groups(self):
+        """[(name, elements)] of the buckets in launch order (reverse parameter order): input of collective_plan."""
+        return [(f"bucket{bi}", sum(p.numel() for p in b)) for bi, b in enumerate(self.buckets)]
+
     def remove(self):
         for h in self._hooks:
             h.remove()
@@ -364,6 +368,29 @@ class _Null:
 
     def __exit__(self, *a):
         return False
+
+
+def collective_plan(groups, world: int, comm_dtype: Optional[torch.dtype] = torch.bfloat16, algo: Optional[str] = None) -> dict:
+    """The gradient exchange of ONE train step as data (bench.py prints it into its JSON line, also as a dry plan on one GPU, so that the
+    first record from a real 8-GPU node describes itself): `groups` = [(name, number of gradient elements)] in launch order - the
+    48 MB buckets of GradBucketReducer or the per-segment groups of GradGroupReducer.  Per collective: payload bytes, and the time its
+    slowest xGMI link needs at 153 GB/s per direction (7 point-to-point links per GPU) for a ring (2 (W - 1) / W of the
+    payload over ONE link) and for the direct reduce-scatter + all-gather pattern (2 / W of the payload over EACH of the W - 1 links)."""
+    algo = algo or default_algo()
+    esize = torch.empty(0, dtype=comm_dtype).element_size() if comm_dtype else 4
+    link = 153e9
+    items, total = [], 0
+    for name, numel in groups:
+        b = _padded(int(numel), max(world, 1)) * esize
+        total += b
+        items.append({"group": str(name), "bytes": b,
+                      "ring_us": round(2.0 * (world - 1) / world * b / link * 1e6, 1) if world > 1 else 0.0,
+                      "direct_us": round(2.0 / world * b / link * 1e6, 1) if world > 1 else 0.0})
+    return {"world": world, "algo": algo, "comm_dtype": str(comm_dtype).replace("torch.", "") if comm_dtype else "float32",
+            "collectives_per_step": len(items) + 1, "gradient_bytes_per_step": total,
+            "loss_norm": "one 5-float all-reduce at the top of the step (global valid counts, dp.GlobalLossNorm)",
+            "ring_us_total": round(sum(i["ring_us"] for i in items), 1), "direct_us_total": round(sum(i["direct_us"] for i in items), 1),
+            "groups": items}
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:

@@ -462,6 +462,17 @@ class GraphedAPTAIStep:
         loss, mse, ce, tvs, pred, _ = self.outs
         return {"loss": loss, "mse_loss": mse, "ce_loss": ce, "tvs_pred": tvs, "phn_fc_pred": pred}
 
+    def plan_groups(self):
+        """[(name, gradient elements)] of the per-segment gradient groups in the order step() hands them to dp.GradGroupReducer
+        (heads, layers L-1 .. 0, front): input of dp.collective_plan."""
+        heads = [gt for p, gt in self.grads.items() if p.requires_grad and any(p is q for q in self.hparams)]
+        front = [gt for p, gt in self.grads.items() if p.requires_grad and not any(p is q for q in self.hparams)]
+        out = [("heads", sum(t.numel() for t in heads))]
+        for i in range(self.cfg.num_hidden_layers - 1, -1, -1):
+            out.append((f"layer{i}", sum(t.numel() for t in self._layer_grad_tensors(i))))
+        out.append(("front", sum(t.numel() for t in front)))
+        return out
+
     def _layer_grad_tensors(self, i: int) -> List[torch.Tensor]:
         """Distinct gradient buffers of layer i (the q/k/v weight and bias gradients are row slices of one buffer each)."""
         out, seen = [], set()
@@ -516,8 +527,12 @@ class BucketedGraphedStep:
 
     DEFAULT_SECONDS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 15, 20, 25, 30)
 
-    def __init__(self, model, optimizer, bucket_samples=None, reducer=None, label_bucket: int = 32):
+    def __init__(self, model, optimizer, bucket_samples=None, reducer=None, label_bucket: int = 32, max_runners: int = 8, log=None):
         self.model, self.opt, self.reducer = model, optimizer, reducer
+        # Every runner holds a capture stream with a salt and a bounds slot (64 of each in the library, csrc/runtime.hip) and several GB of
+        # saved activations and graph pools; a real corpus spans 13 length buckets x several label widths (+ a short last batch), so the
+        # cache is bounded: beyond `max_runners` the least recently used runner is closed (its graphs are re-captured if its shape returns).
+        self.max_runners, self.log, self.evictions = max(1, int(max_runners)), log, 0
         self.kind = "pr" if isinstance(model, Wav2Vec2_PR) else "aptai"
         self.buckets = sorted(bucket_samples) if bucket_samples else [16000 * s for s in self.DEFAULT_SECONDS]
         self.label_bucket = label_bucket
@@ -558,11 +573,20 @@ class BucketedGraphedStep:
         g_s, g_b = self.w._geometry(B, S), self.w._geometry(B, Sb)
         padded = self._padded(batch, Sb, g_b.T)
         key = (B, Sb) + ((padded["phoneme_labels"].shape[1],) if self.kind == "pr" else ())
-        r = self.runners.get(key)
+        r = self.runners.pop(key, None)
         if r is None:
+            while len(self.runners) >= self.max_runners:
+                old_key = next(iter(self.runners))              # dicts keep insertion order: the first key is the least recently used
+                self.runners.pop(old_key).close()
+                self.evictions += 1
+                if self.log is not None:
+                    self.log(f"[graphed] closed the runner of shape {old_key} (cache of {self.max_runners} is full)")
             dev = next(self.model.parameters()).device
             r = GraphedAPTAIStep(self.model, self.opt, {k: v.to(dev) for k, v in padded.items()}, reducer=self.reducer)
-            self.runners[key] = r
+            if self.log is not None:
+                self.log(f"[graphed] captured shape {key}: {len(self.runners) + 1} runner(s), "
+                         f"{torch.cuda.memory_allocated(dev) / 2 ** 30:.1f} GiB allocated")
+        self.runners[key] = r                                   # (re-)inserted last = most recently used
         r.set_bounds(g_s.Tl[0], g_s.T)
         out = r.step(padded)
         T = g_s.T

@@ -11,9 +11,7 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-# the opt-in column-split launch of aptai_gemm_bf16 is exercised by the GPU suite (bit-identical to the single launch:
-# tests/test_gpu_gemm.py::test_split_column_launch_equals_the_single_launch); the library reads the variable at its first GEMM
-os.environ.setdefault("APTAI_GEMM_SPLITN", "1")
+# (the suite runs with the library's DEFAULT environment; knobs are exercised in processes of their own: tests/test_gpu_env_knobs.py)
 
 
 def pytest_configure(config):

@@ -245,35 +245,6 @@ def test_stream_k_256_tiles_against_fp32_and_the_tile_kernels(M, N, K):
     ops.gemm_sk_check()
 
 
-@pytest.mark.parametrize("km", [False, True])
-def test_split_column_launch_equals_the_single_launch(km):
-    """[8192] x 3072 outputs are 1.5 rounds of 256 x 256 tiles: under APTAI_GEMM_SPLITN=1 aptai_gemm_bf16 runs them as a 256-tile launch over
-    columns [0, 2048) plus a 128-tile launch over [2048, 3072) (the variable is read at the first GEMM of the process: conftest sets it).  Against the forced single 128-tile launch: the same dropout mask (the element index is the
-    whole output's) and the same values, with every epilogue pointer (bias, residual / aux, second output) offset correctly."""
-    from aptai_amd import ops
-    M, N, K = 8192, 3072, 768
-    g = torch.Generator(device="cuda").manual_seed(5)
-    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g).to(torch.bfloat16)
-    a = rnd(M, K)
-    b = rnd(K, N) if km else rnd(N, K)
-    bias = torch.randn(N, device="cuda", generator=g)
-    if km:                                                  # the FFN2-dgrad form: x aux
-        aux = rnd(M, N)
-        one = ops.gemm(a, b, M, N, K, b_kmajor=True, mul_aux=aux, tile=128)
-        two = ops.gemm(a, b, M, N, K, b_kmajor=True, mul_aux=aux)
-        assert torch.equal(one.view(torch.int16), two.view(torch.int16))
-        return
-    pre1 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    pre2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    kw = dict(bias=bias, gelu=True, pre_dgelu=True, dropout_p=0.1, seed=7)
-    one = ops.gemm(a, b, M, N, K, out_pre=pre1, tile=128, **kw)
-    two = ops.gemm(a, b, M, N, K, out_pre=pre2, **kw)
-    torch.cuda.synchronize()
-    assert torch.equal((one == 0), (two == 0)) and 0.08 < (two == 0).float().mean().item() < 0.13
-    assert torch.equal(one.view(torch.int16), two.view(torch.int16))
-    assert torch.equal(pre1.view(torch.int16), pre2.view(torch.int16))
-
-
 @pytest.mark.parametrize("km", [False, True], ids=["nt", "nn"])
 @pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (4096, 3072, 1024), (1000, 2304, 128), (300, 200, 64)])
 def test_256x192_tile_equals_the_128_tile_bit_for_bit(M, N, K, km):

@@ -372,3 +372,36 @@ def test_bucketed_pr_step_gradients_equal_the_eager_step_from_identical_paramete
         model.wav2vec2._cache.clear()
         if not exact:
             print(f"[bands] bucketed PR step vs eager, other padded frame count: worst per-parameter gradient rel-L2 {worst:.2e}")
+
+
+def test_bucketed_runner_cache_is_bounded_and_eviction_changes_nothing():
+    """BucketedGraphedStep(max_runners=...): beyond the cap the least recently used runner is closed (salt / bounds slots of the library and
+    GBs of saved activations are per runner; a corpus spans many (length bucket, label width) shapes) and re-captured if its shape returns.
+    Alternating two buckets through a cache of ONE runner must give the losses of an unbounded cache, bit for bit, and release the
+    stream-bound slots it used (a 65th binding would be refused)."""
+    from aptai_amd import hostlogic
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.graphed import BucketedGraphedStep
+    from aptai_amd.optim import Adam
+    from aptai_amd.train_aptai import SyntheticHPRC
+    from oracle import synth
+    from test_gpu_aptai import _build
+    cfg = W2V2Config.base(num_hidden_layers=2, hidden_dropout=0., activation_dropout=0., attention_dropout=0.,
+                          feat_proj_dropout=0., final_dropout=0., layerdrop=0., apply_spec_augment=False, vocab_size=46)
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), 0)
+    batches = []
+    for i, sec in enumerate((1.3, 1.9, 1.4, 2.0)):
+        ds = SyntheticHPRC(2, sec, vary_length=True, seed=20 + i, cfg=cfg)
+        batches.append(hostlogic.collate_aptai([ds[j] for j in range(2)]))
+    rec = {}
+    for cap in (8, 1):
+        model = _build(cfg, sd, tv_drop=0.0, phn_drop=0.0)
+        model.train()
+        opt = Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4).publish_to(model)
+        lines = []
+        with BucketedGraphedStep(model, opt, bucket_samples=[24000, 32000], max_runners=cap, log=lines.append) as runner:
+            rec[cap] = [runner.step(b)["loss"].item() for b in batches]
+            assert len(runner.runners) == min(cap, 2)
+            assert runner.evictions == (0 if cap == 8 else 3), runner.evictions
+        assert sum("captured shape" in l for l in lines) == (2 if cap == 8 else 4)
+    assert rec[1] == rec[8], rec
