@@ -21,6 +21,12 @@ namespace {
 
 __device__ __forceinline__ float bf_round(float x) { return bf2f(f2bf(x)); }
 
+// erf-form GELU of the exact mode.  erf by Abramowitz-Stegun 7.1.26 with an IEEE reciprocal and the fast exponential (common.h erf_fast:
+// |error| <= 1.5e-7 absolute, i.e. about one fp32 ulp of the GELU value for |x| of order 1): libm's erff cost ~40 vector instructions per
+// element and made the two passes that apply a GELU to the conv stack's 260 M activations VALU-bound (conv0_exact_kernel 0.61 ms per
+// call for 1 GB of output; tests/test_gpu_exact.py pins the mode end to end, indices and hidden states).
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+
 // pieces of one value: p[0] >= p[1] >= p[2] in magnitude, p[0] + p[1] (+ p[2]) = x up to 2^-17 (2^-25)
 __device__ __forceinline__ void split3(float x, float& h, float& m, float& l) {
     h = bf_round(x);
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void split_kernel(SplitArgs a) {
         float h[8], m[8], l[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            if (a.act == 1) v[r] = gelu_erf(v[r]);
+            if (a.act == 1) v[r] = gelu_exact(v[r]);
             split3(v[r], h[r], m[r], l[r]);
         }
         bf16_t* dst = a.out + row * a.ldo + (long)(c0 >> 6) * (64 * a.pieces) + (c0 & 63);
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs a) {
         if (a.bias) v += *(const f32x4*)(a.bias + c0);
         if (a.act == 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
         }
         if (a.res) v += *(const f32x4*)(a.res + row * a.ldr + c0);
         if (a.lens) {
@@ -126,6 +132,65 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
     for (int k = lane; k < Tp; k += 64) p[k] = k < len ? p[k] * inv : 0.f;
 }
 
+// softmax of one query row straight into the split (activation-side) layout of the probabilities: the P . V product of the exact
+// attention reads its A operand as bf16 pieces, so the fp32 probabilities are never stored (round 4: softmax in place + split_kernel
+// moved 1.1 GB per layer at 16 x 10 s, this pass 0.5 GB).  One wave per row; a lane owns 8 consecutive keys per 512-key chunk
+// (two 16-byte loads, `pieces` 16-byte stores, exactly split_kernel's addressing).  Same arithmetic as softmax_rows_kernel + split3.
+template <int NCH>
+__global__ __launch_bounds__(256) void softmax_split_kernel(const float* __restrict__ s, const int* __restrict__ lens, long rows_per_b,
+                                                            long rows, int Tp, int pieces, bf16_t* __restrict__ out, long ldo) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int len = lens[row / rows_per_b];
+    const float* p = s + row * Tp;
+    float v[NCH][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k0 = (c * 64 + lane) * 8;
+        if (k0 < Tp) {
+            const f32x4 a0 = *(const f32x4*)(p + k0), a1 = *(const f32x4*)(p + k0 + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[c][r] = a0[r]; v[c][4 + r] = a1[r]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[c][r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) if (k0 + r < len) mx = fmaxf(mx, v[c][r]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k0 = (c * 64 + lane) * 8;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float e = (k0 + r < len) ? expf(v[c][r] - mx) : 0.f;
+            v[c][r] = e;
+            sum += e;
+        }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k0 = (c * 64 + lane) * 8;
+        if (k0 >= Tp) continue;
+        float h[8], m[8], l[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) split3((k0 + r < len) ? v[c][r] * inv : 0.f, h[r], m[r], l[r]);
+        bf16_t* dst = out + row * ldo + (long)(k0 >> 6) * (64 * pieces) + (k0 & 63);
+        auto put = [&](int piece, const float (&q)[8]) {
+            *(u32x4*)(dst + piece * 64) = (u32x4){pack2bf(q[0], q[1]), pack2bf(q[2], q[3]), pack2bf(q[4], q[5]), pack2bf(q[6], q[7])};
+        };
+        put(0, h);
+        if (pieces == 3) { put(1, h); put(2, m); }
+        else { put(1, h); put(2, m); put(3, m); put(4, h); put(5, l); }
+    }
+}
+
 // ---- first conv layer with fp32 output and the erf GELU (one wave per frame, lane = 8 channels; the training-path kernel of
 // conv.hip writes bf16 and uses the logistic GELU).  mode 0: GroupNorm statistics (mean, rstd per (b, channel)) from `stats`;
 // mode 1: LayerNorm over the 512 channels of the frame.
@@ -141,6 +206,25 @@ __global__ __launch_bounds__(256) void conv0_exact_kernel(Conv0xArgs a) {
     const int b = blockIdx.y;
     const float* xb = a.audio + (long)b * a.S;
     float* ob = a.out + (long)b * a.T_alloc * C0;
+    // taps, bias and the affine of this lane's 8 channels live in registers for the whole launch (round 4: the first form re-loaded the
+    // 80 taps and the per-channel parameters from memory for every frame: 2.5 ms per call at 16 x 10 s, 8 % of the exact-mode step)
+    float w[8][KW], bs[8], sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = lane * 8 + j;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) w[j][k] = a.w[c * KW + k];
+        bs[j] = a.bias ? a.bias[c] : 0.f;
+        if (a.mode == 0) {                       // GroupNorm: (v - mean) * rstd * gamma + beta with the statistics of (b, channel), as written
+            sc[j] = a.stats[((long)b * 2 + 1) * C0 + c];
+            sh[j] = a.stats[((long)b * 2 + 0) * C0 + c];
+        } else {
+            sc[j] = 0.f; sh[j] = 0.f;
+        }
+    }
+    float gm[8], bt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gm[j] = a.gamma[lane * 8 + j]; bt[j] = a.beta[lane * 8 + j]; }
     for (int t = blockIdx.x * 4 + wave; t < a.T_alloc; t += gridDim.x * 4) {
         float o[8];
 #pragma unroll
@@ -151,19 +235,14 @@ __global__ __launch_bounds__(256) void conv0_exact_kernel(Conv0xArgs a) {
             for (int k = 0; k < KW; ++k) xs[k] = xb[(long)t * STRIDE + k];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int c = lane * 8 + j;
                 float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < KW; ++k) acc = fmaf(xs[k], a.w[c * KW + k], acc);
-                v[j] = acc + (a.bias ? a.bias[c] : 0.f);
+                for (int k = 0; k < KW; ++k) acc = fmaf(xs[k], w[j][k], acc);
+                v[j] = acc + bs[j];
             }
             if (a.mode == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = lane * 8 + j;
-                    const float mu = a.stats[((long)b * 2 + 0) * C0 + c], rs = a.stats[((long)b * 2 + 1) * C0 + c];
-                    o[j] = gelu_erf((v[j] - mu) * rs * a.gamma[c] + a.beta[c]);
-                }
+                for (int j = 0; j < 8; ++j) o[j] = gelu_exact((v[j] - sh[j]) * sc[j] * gm[j] + bt[j]);
             } else {
                 float s = 0.f;
 #pragma unroll
@@ -174,10 +253,7 @@ __global__ __launch_bounds__(256) void conv0_exact_kernel(Conv0xArgs a) {
                 for (int j = 0; j < 8; ++j) { const float d = v[j] - mu; q += d * d; }
                 const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / C0) + a.eps);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = lane * 8 + j;
-                    o[j] = gelu_erf((v[j] - mu) * rs * a.gamma[c] + a.beta[c]);
-                }
+                for (int j = 0; j < 8; ++j) o[j] = gelu_exact((v[j] - mu) * rs * gm[j] + bt[j]);
             }
         }
         float* dst = ob + (long)t * C0 + lane * 8;
@@ -226,6 +302,23 @@ extern "C" int aptai_softmax_rows_f32(float* s, const int32_t* lens, int64_t B, 
     APTAI_LAUNCH(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, lens, (long)(heads * Tp), rows,
                  (int)Tp);
     APTAI_CHECK_LAUNCH("softmax_rows_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_softmax_split_f32(const float* s, const int32_t* lens, int64_t B, int64_t heads, int64_t Tp, int pieces, void* out,
+                                       int64_t ldo, void* stream) {
+    APTAI_REQUIRE(s && lens && out && B > 0 && heads > 0, "aptai_softmax_split_f32: bad arguments");
+    APTAI_REQUIRE(Tp > 0 && Tp % 64 == 0 && Tp <= 2048, "aptai_softmax_split_f32: Tp=%ld must be a multiple of 64, at most 2048", (long)Tp);
+    APTAI_REQUIRE(pieces == 3 || pieces == 6, "aptai_softmax_split_f32: pieces must be 3 or 6");
+    APTAI_REQUIRE(ldo >= Tp * pieces && ldo % 8 == 0 && (uintptr_t)s % 16 == 0 && (uintptr_t)out % 16 == 0, "aptai_softmax_split_f32: layout");
+    const long rows = B * heads * Tp;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int nch = (int)((Tp + 511) / 512);
+    if (nch == 1) APTAI_LAUNCH(softmax_split_kernel<1>, grid, block, 0, (hipStream_t)stream, s, lens, (long)(heads * Tp), rows, (int)Tp, pieces, (bf16_t*)out, (long)ldo);
+    else if (nch == 2) APTAI_LAUNCH(softmax_split_kernel<2>, grid, block, 0, (hipStream_t)stream, s, lens, (long)(heads * Tp), rows, (int)Tp, pieces, (bf16_t*)out, (long)ldo);
+    else if (nch == 3) APTAI_LAUNCH(softmax_split_kernel<3>, grid, block, 0, (hipStream_t)stream, s, lens, (long)(heads * Tp), rows, (int)Tp, pieces, (bf16_t*)out, (long)ldo);
+    else APTAI_LAUNCH(softmax_split_kernel<4>, grid, block, 0, (hipStream_t)stream, s, lens, (long)(heads * Tp), rows, (int)Tp, pieces, (bf16_t*)out, (long)ldo);
+    APTAI_CHECK_LAUNCH("softmax_split_kernel");
     return APTAI_OK;
 }
 

@@ -222,34 +222,55 @@ __global__ void embed_pe_fwd_kernel(const int* __restrict__ ids, const float* __
 }
 // ORDER-FIXED (round 4; was one float atomicAdd per element: the sum over the rows that share a phoneme id had no defined order, so
 // phn_emb_layer.weight.grad changed in its last bits from launch to launch).  One block per row; the block of the FIRST row that
-// carries an id owns that id's gradient row and adds the later rows with the same id in row order; other blocks leave at once.
+// carries an id owns that id's gradient row, collects which later rows carry the same id as ballot masks (row order), then every
+// thread adds its column of those rows in mask order, four independent loads at a time (a fixed order: same inputs, same bits).
 __global__ __launch_bounds__(128) void embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dout, float* __restrict__ demb,
                                                         int rows, int D, float scale_keep, uint32_t s0, uint32_t s1, uint32_t thr) {
-    __shared__ int sid[1024];
+    __shared__ unsigned long long masks[128];                       // rows r0 + 64 m .. + 64 : up to 8192 rows behind r0
+    __shared__ int list[8192];                                      // the rows that carry this id, ascending
+    __shared__ int nlist;
     const int r0 = blockIdx.x;
     const int id = ids[r0];
     if (id == 0) return;                                            // padding_idx = 0 receives no gradient (block-uniform)
     int dup = 0;
     for (int i = threadIdx.x; i < r0; i += blockDim.x) dup |= ids[i] == id;
     if (__syncthreads_or(dup)) return;
-    for (int d0 = 0; d0 < D; d0 += blockDim.x) {
-        const int d = d0 + threadIdx.x;
-        float acc = 0.f;
-        for (int base = r0; base < rows; base += 1024) {
-            const int n = rows - base < 1024 ? rows - base : 1024;
-            __syncthreads();
-            for (int i = threadIdx.x; i < n; i += blockDim.x) sid[i] = ids[base + i];
-            __syncthreads();
-            if (d < D)
-                for (int i = 0; i < n; ++i) {
-                    if (sid[i] != id) continue;                     // block-uniform
-                    const long e = (long)(base + i) * D + d;
-                    float v = dout[e];
-                    if (thr) v = drop_keep((uint64_t)e, s0, s1, thr) ? v * scale_keep : 0.f;
-                    acc += v;
-                }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int nmask = (rows - r0 + 63) >> 6;
+    nmask = nmask < 128 ? nmask : 128;
+    for (int m = wave; m < nmask; m += 2) {
+        const int r = r0 + m * 64 + lane;
+        const unsigned long long bal = __ballot(r < rows && ids[r] == id);
+        if (lane == 0) masks[m] = bal;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int m = 0; m < nmask; ++m) {
+            unsigned long long bits = masks[m];
+            while (bits) {
+                list[n++] = r0 + m * 64 + __builtin_ctzll(bits);
+                bits &= bits - 1;
+            }
         }
-        if (d < D) demb[(long)id * D + d] = acc;
+        nlist = n;
+    }
+    __syncthreads();
+    const int n = nlist;
+    auto value = [&](int k, int d) {
+        if (k >= n) return 0.f;
+        const long e = (long)list[k] * D + d;
+        float v = dout[e];
+        if (thr) v = drop_keep((uint64_t)e, s0, s1, thr) ? v * scale_keep : 0.f;
+        return v;
+    };
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < n; k += 4) {                            // four independent loads, added in list order
+            const float v0 = value(k, d), v1 = value(k + 1, d), v2 = value(k + 2, d), v3 = value(k + 3, d);
+            acc = (((acc + v0) + v1) + v2) + v3;
+        }
+        demb[(long)id * D + d] = acc;
     }
 }
 
@@ -592,7 +613,7 @@ extern "C" int aptai_embed_pe_fwd(const int32_t* ids, const float* emb, const fl
 }
 extern "C" int aptai_embed_bwd(const int32_t* ids, const float* dout, float* demb_zeroed, int64_t rows, int64_t D, float dropout_p,
                                uint64_t seed, void* stream) {
-    APTAI_REQUIRE(ids && dout && demb_zeroed && rows > 0, "aptai_embed_bwd: bad arguments");
+    APTAI_REQUIRE(ids && dout && demb_zeroed && rows > 0 && rows <= 8192, "aptai_embed_bwd: bad arguments (at most 8192 rows)");
     const uint32_t thr = drop_thr16(dropout_p);
     APTAI_LAUNCH(embed_bwd_kernel, dim3((unsigned)rows), dim3(128), 0, (hipStream_t)stream, ids, dout, demb_zeroed, (int)rows, (int)D,
                  drop_scale(thr), (uint32_t)seed, (uint32_t)(seed >> 32), thr);

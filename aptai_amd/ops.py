@@ -326,6 +326,14 @@ def softmax_rows_f32(s32, lens_i32, B, heads, Tp):
     return s32
 
 
+def softmax_split_f32(s32, lens_i32, B, heads, Tp, pieces):
+    """Masked softmax of the fp32 scores [B][heads][Tp][Tp] written as split bf16 pieces [B heads Tp][pieces Tp] (aptai_softmax_split_f32)."""
+    _dev(s32, lens_i32)
+    out = torch.empty((B * heads * Tp, pieces * Tp), device=s32.device, dtype=torch.bfloat16)
+    _lib.call("aptai_softmax_split_f32", s32.data_ptr(), lens_i32.data_ptr(), B, heads, Tp, pieces, out.data_ptr(), pieces * Tp, _stream())
+    return out
+
+
 def conv0_fwd_f32(audio, weight, bias, gamma, beta, mode, out32, T_real, T_alloc, stats, eps=1e-5):
     _dev(audio, weight, bias, gamma, beta, out32, stats)
     B, S = audio.shape
@@ -337,8 +345,12 @@ def conv0_fwd_f32(audio, weight, bias, gamma, beta, mode, out32, T_real, T_alloc
 def gemm_split(a_s: torch.Tensor, w_s: torch.Tensor, M: int, N: int, K: int, pieces: int, *, lda=None, bias=None, residual_f32=None,
                out=None, ldc=None) -> torch.Tensor:
     """fp32 C[M][N] = A . W^T (+ bias) (+ fp32 residual) from split operands (split_f32): one NT launch of K' = pieces * K."""
+    # fp32-output launches name their tile (include/aptai_hip.h); whole rounds of 256 x 256 tiles where the output has them (the conv
+    # stack's [B x 16384 ...] x 512 outputs: 3 x the bf16 work at K' = 3 K is the longest loop of the build), 128-row tiles elsewhere
+    t256 = -(-M // 256) * -(-N // 256)
+    tile = 256 if (M >= 256 and N >= 256 and t256 >= 1024) else 128
     return gemm(a_s, w_s, M, N, K * pieces, lda=(lda * pieces if lda is not None else None), out_f32=True, bias=bias,
-                residual_f32=residual_f32, out=out, ldc=ldc, tile=128)
+                residual_f32=residual_f32, out=out, ldc=ldc, tile=tile)
 
 
 # ----------------------------------------------------------------------------- LayerNorm

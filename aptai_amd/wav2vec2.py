@@ -910,20 +910,31 @@ class Wav2Vec2Model(nn.Module):
             return w
         return self._cached(("exact", P), params, build)
 
-    def _exact_attention(self, qkv32, lens_i32, g):
-        """softmax(Q K^T / sqrt(d) + key mask) V per head on the fp32 matrix instruction (HF:438-548): scores [B][heads][Tp][Tp] fp32."""
+    def _exact_attention(self, qkv32, lens_i32, g, P=3):
+        """softmax(Q K^T / sqrt(d) + key mask) V per head (HF:438-548) at fp32-class accuracy.  Round 4: both products as SPLIT-OPERAND
+        bf16 GEMMs, batched over (utterance, head) - two launches per layer on the 2.5 PF pipe instead of 24 on the fp32 matrix
+        instruction (157 TF; the exact-mode step spent 10 of its 27 ms there).  Per head the 64 feature columns are exactly one K-tile
+        of aptai_split_f32's interleaved layout, so head h of the split Q / K is the column block [h * 64 P, (h + 1) * 64 P): the batch
+        strides of aptai_gemm_bf16 walk heads and utterances, nothing is re-packed.  Scores [B][heads][Tp][Tp] stay fp32 (softmax
+        in fp32, masked keys exactly 0); the probabilities leave the softmax pass already split like every other activation, V is transposed once so that its
+        key axis is the contiguous K of an NT product."""
         cfg = self.config
-        H, heads, B, Tp = cfg.hidden_size, cfg.num_attention_heads, g.B, g.Tp
+        H, heads, B, Tp, M = cfg.hidden_size, cfg.num_attention_heads, g.B, g.Tp, g.M
         d = H // heads
-        s32 = torch.empty((B, heads, Tp, Tp), device=qkv32.device, dtype=torch.float32)
-        for h in range(heads):
-            ops.sgemm(qkv32[:, h * d:], 3 * H, 1, qkv32[:, H + h * d:], 1, 3 * H, Tp, Tp, d, out=s32[:, h], ldc=Tp, alpha=d ** -0.5,
-                      batch=B, bsa=Tp * 3 * H, bsb=Tp * 3 * H, bsc=heads * Tp * Tp, split_k=1)
-        ops.softmax_rows_f32(s32, lens_i32, B, heads, Tp)
-        ctx = torch.empty((g.M, H), device=qkv32.device, dtype=torch.float32)
-        for h in range(heads):
-            ops.sgemm(s32[:, h], Tp, 1, qkv32[:, 2 * H + h * d:], 3 * H, 1, Tp, d, Tp, out=ctx[:, h * d:], ldc=H, batch=B,
-                      bsa=heads * Tp * Tp, bsb=Tp * 3 * H, bsc=Tp * H, split_k=1)
+        if d != 64:
+            raise NotImplementedError("the exact attention is built for head_dim 64 (one K-tile of the split layout per head)")
+        dev = qkv32.device
+        qs = ops.split_f32(qkv32, P, cols=H)                                   # [M][P H]  (hi, hi, lo per 64 columns)
+        ks = ops.split_f32(qkv32[:, H:], P, cols=H, weight_side=True)           # [M][P H]  (hi, lo, hi)
+        s32 = torch.empty((B, heads, Tp, Tp), device=dev, dtype=torch.float32)
+        ops.gemm(qs, ks, Tp, Tp, P * d, lda=P * H, ldb=P * H, out=s32, ldc=Tp, out_f32=True, alpha=d ** -0.5, tile=128,
+                 batch=dict(outer=B, inner=heads, a=(Tp * P * H, P * d), b=(Tp * P * H, P * d), c=(heads * Tp * Tp, Tp * Tp)))
+        ps = ops.softmax_split_f32(s32, lens_i32, B, heads, Tp, P)              # [B heads Tp][P Tp]: softmax + split in one pass
+        vt = qkv32[:, 2 * H:].reshape(B, Tp, heads, d).permute(0, 2, 3, 1).contiguous()            # [B][heads][d][Tp] fp32
+        vts = ops.split_f32(vt.view(B * heads * d, Tp), P, weight_side=True)    # [B heads d][P Tp]
+        ctx = torch.empty((M, H), device=dev, dtype=torch.float32)
+        ops.gemm(ps, vts, Tp, d, P * Tp, lda=P * Tp, ldb=P * Tp, out=ctx, ldc=H, out_f32=True, tile=128,
+                 batch=dict(outer=B, inner=heads, a=(heads * Tp * P * Tp, Tp * P * Tp), b=(heads * d * P * Tp, d * P * Tp), c=(Tp * H, d)))
         return ctx
 
     def _forward_exact(self, audio, g, lens_i32, P, output_hidden_states):
@@ -987,7 +998,7 @@ class Wav2Vec2Model(nn.Module):
             else:
                 a_in = h
             qkv = ops.gemm_split(ops.split_f32(a_in, P), w.wqkv, M, 3 * H, H, P, bias=w.bqkv)
-            ctx = self._exact_attention(qkv, lens_i32, g)
+            ctx = self._exact_attention(qkv, lens_i32, g, P)
             s1 = ops.gemm_split(ops.split_f32(ctx, P), w.wo, M, H, H, P, bias=w.bo, residual_f32=h)
             if cfg.do_stable_layer_norm:
                 _, f_in = ops.layernorm_fwd_f32in(s1, ln2.weight, ln2.bias, eps, want_bf16=False)

@@ -129,6 +129,11 @@ int aptai_bias_act_res_f32(const float* x, int64_t ldx, const float* bias, const
 /* softmax over keys, in place on fp32 scores s[B][heads][Tp][Tp]; keys >= lens[b] get probability 0 (HF:452-461 under the
  * finfo.min key mask of HF:1018-1036). */
 int aptai_softmax_rows_f32(float* s, const int32_t* lens, int64_t B, int64_t heads, int64_t Tp, void* stream);
+/* The same masked softmax written straight into the split (activation-side) layout [row][Tp/64][piece][64] of its probabilities - the A
+ * operand of the exact attention's P . V product (aptai_amd/wav2vec2.py _exact_attention; replaces torch softmax at HF:452-461 followed by
+ * aptai_split_f32: the fp32 probabilities are never stored).  s fp32 [B][heads][Tp][Tp]; out bf16, row pitch ldo >= pieces * Tp. */
+int aptai_softmax_split_f32(const float* s, const int32_t* lens, int64_t B, int64_t heads, int64_t Tp, int pieces, void* out, int64_t ldo,
+                            void* stream);
 /* Conv1d(1,512,10,5) + GroupNorm / LayerNorm + erf GELU with FP32 output [B][T_alloc][512] (HF:260-323); `stats` = the (mean, rstd)
  * block [B][2][512] of aptai_conv0_fwd in group mode (mode 0), unused in layer mode (mode 1). */
 int aptai_conv0_fwd_f32(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias, const float* gamma,
