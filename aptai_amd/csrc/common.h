@@ -123,6 +123,21 @@ __device__ __forceinline__ float gelu_fast_grad(float x) {
     return fmaf(fmaf(-s, s, s), xc * q, s);                             // s + x s (1 - s) d/dx[x p(x^2)]
 }
 
+// ---------------------------------------------------------------------------------- exact-index mode (csrc/exact.hip, split-out epilogue)
+__device__ __forceinline__ float bf_round(float x) { return bf2f(f2bf(x)); }
+// pieces of one value: p[0] >= p[1] >= p[2] in magnitude, p[0] + p[1] (+ p[2]) = x up to 2^-17 (2^-25)
+__device__ __forceinline__ void split3(float x, float& h, float& m, float& l) {
+    h = bf_round(x);
+    const float r1 = x - h;             // exact in fp32
+    m = bf_round(r1);
+    l = bf_round(r1 - m);
+}
+// erf-form GELU of the exact mode.  erf by Abramowitz-Stegun 7.1.26 with an IEEE reciprocal and the fast exponential (erf_fast above:
+// |error| <= 1.5e-7 absolute, about one fp32 ulp of the GELU value for |x| of order 1): libm's erff cost ~40 vector instructions per
+// element and made the passes that apply a GELU to the conv stack's 260 M activations VALU-bound (conv0_exact_kernel 0.61 ms per call
+// for 1 GB of output; tests/test_gpu_exact.py pins the mode end to end, indices and hidden states).
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+
 // ---------------------------------------------------------------------------------- counter RNG (dropout)
 // One 32-bit hash per PAIR of elements (16 bits each): keep iff half >= thr16.  Forward and backward
 // regenerate the same mask from (seed, logical element index), whatever their thread mapping.

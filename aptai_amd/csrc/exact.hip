@@ -19,22 +19,6 @@
 
 namespace {
 
-__device__ __forceinline__ float bf_round(float x) { return bf2f(f2bf(x)); }
-
-// erf-form GELU of the exact mode.  erf by Abramowitz-Stegun 7.1.26 with an IEEE reciprocal and the fast exponential (common.h erf_fast:
-// |error| <= 1.5e-7 absolute, i.e. about one fp32 ulp of the GELU value for |x| of order 1): libm's erff cost ~40 vector instructions per
-// element and made the two passes that apply a GELU to the conv stack's 260 M activations VALU-bound (conv0_exact_kernel 0.61 ms per
-// call for 1 GB of output; tests/test_gpu_exact.py pins the mode end to end, indices and hidden states).
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
-
-// pieces of one value: p[0] >= p[1] >= p[2] in magnitude, p[0] + p[1] (+ p[2]) = x up to 2^-17 (2^-25)
-__device__ __forceinline__ void split3(float x, float& h, float& m, float& l) {
-    h = bf_round(x);
-    const float r1 = x - h;             // exact in fp32
-    m = bf_round(r1);
-    l = bf_round(r1 - m);
-}
-
 struct SplitArgs {
     const float* x; long ldx;
     bf16_t* out; long ldo;

@@ -86,7 +86,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
         g.A += bo * g.sA[0] + bi * g.sA[1];
         g.B += bo * g.sB[0] + bi * g.sB[1];
         const long co = bo * g.sC[0] + bi * g.sC[1];
-        g.C = OUT_F32 ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
+        g.C = (OUT_F32 && !(g.flags & APTAI_EPI_SPLIT_OUT)) ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
         if (g.out_pre) g.out_pre += co;
         if (g.bias) g.bias += bo * g.sBias[0] + bi * g.sBias[1];
         if (g.residual) g.residual += bo * g.sR[0] + bi * g.sR[1];
@@ -412,6 +412,21 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
                     const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+                }
+                if (flags & APTAI_EPI_SPLIT_OUT) {               // exact-index mode: the result leaves as the next GEMM's split A operand
+                    float h[8], md[8], lw[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (flags & APTAI_EPI_GELU) v[r] = gelu_exact(v[r]);
+                        split3(v[r], h[r], md[r], lw[r]);
+                    }
+                    bf16_t* dst = (bf16_t*)g.C + (long)m * g.ldc + (long)(n >> 6) * (64 * g.split_pieces) + (n & 63);
+                    auto put = [&](int piece, const float (&q)[8]) {
+                        *(u32x4*)(dst + piece * 64) = (u32x4){pack2bf(q[0], q[1]), pack2bf(q[2], q[3]), pack2bf(q[4], q[5]), pack2bf(q[6], q[7])};
+                    };
+                    put(0, h); put(1, h); put(2, md);            // activation side: hi hi lo | hi hi mid mid hi low
+                    if (g.split_pieces == 6) { put(3, md); put(4, h); put(5, lw); }
+                    return;
                 }
                 float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
                 *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
@@ -1455,6 +1470,10 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     if (d->flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) APTAI_REQUIRE(d->aux != nullptr, "aptai_gemm_bf16: EPI_DGELU / EPI_MUL_AUX without aux");
     if (d->flags & APTAI_EPI_PRE_DGELU) APTAI_REQUIRE(d->out_pre != nullptr && (d->flags & APTAI_EPI_GELU), "aptai_gemm_bf16: EPI_PRE_DGELU needs EPI_GELU and out_pre");
 
+    if (d->flags & APTAI_EPI_SPLIT_OUT)
+        APTAI_REQUIRE(d->out_f32 && d->tile == 128 && !d->a_kmajor && d->split_k <= 1 && !d->accumulate && (d->split_out_pieces == 3 || d->split_out_pieces == 6) &&
+                      d->ldc >= d->split_out_pieces * d->N && d->N % 8 == 0,
+                      "aptai_gemm_bf16: EPI_SPLIT_OUT needs out_f32, tile 128, 3 or 6 pieces and ldc >= pieces * N (bf16 elements)");
     APTAI_REQUIRE(d->colscale_n >= 0 && d->colscale_n % 8 == 0 && d->colscale_n <= d->N && (d->colscale_n == 0 || !d->out_f32),
                   "aptai_gemm_bf16: colscale_n must be a multiple of 8 within N, bf16 output only");
     memset(&g, 0, sizeof(g));
@@ -1474,6 +1493,7 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     if (g.thr16 == 0) g.flags &= ~APTAI_EPI_DROPOUT;
     g.alpha = d->alpha;
     g.colscale_n = d->colscale_n; g.colscale = d->colscale;
+    g.split_pieces = d->split_out_pieces;
     g.hash_ld = d->N; g.hash_n0 = 0;
     g.tiles_m = (int)ceil_div(d->M, BM);
     g.tiles_n = (int)ceil_div(d->N, BN);

@@ -50,6 +50,7 @@ struct GemmArgs {
     long hash_ld; int hash_n0;  // dropout element index = m * hash_ld + hash_n0 + n: a launch that covers columns [hash_n0, hash_n0 + N) of a
                                 // wider output (aptai_gemm_bf16 splits some) draws the masks of the whole one
     int colscale_n; float colscale;   // columns [0, colscale_n) of the bf16 output are multiplied by colscale (after alpha / bias)
+    int split_pieces;                 // APTAI_EPI_SPLIT_OUT: 3 or 6 bf16 pieces per fp32 result (C is bf16, ldc in bf16 elements)
     // 2-level batching: blockIdx.y = outer * nb_inner + inner; element offsets per level
     int nb_inner;
     long sA[2], sB[2], sC[2], sBias[2], sR[2], sAux[2];

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_DGELU, EPI_ALPHA, EPI_PRE_DGELU, EPI_MUL_AUX, EPI_RESIDUAL_F32 = 1, 2, 4, 8, 16, 32, 64, 128, 256
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_DGELU, EPI_ALPHA, EPI_PRE_DGELU, EPI_MUL_AUX, EPI_RESIDUAL_F32, EPI_SPLIT_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 c_void_p, c_i64, c_int, c_float, c_u64 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
                                           ctypes.c_uint64)
@@ -28,7 +28,7 @@ class GemmDesc(ctypes.Structure):
                 ("batch_stride_a", c_i64 * 2), ("batch_stride_b", c_i64 * 2), ("batch_stride_c", c_i64 * 2),
                 ("batch_stride_bias", c_i64 * 2), ("batch_stride_res", c_i64 * 2), ("batch_stride_aux", c_i64 * 2),
                 ("tile", c_int), ("colscale_n", c_int), ("colscale", c_float),
-                ("sk_workspace", c_void_p), ("sk_workspace_bytes", c_i64)]
+                ("sk_workspace", c_void_p), ("sk_workspace_bytes", c_i64), ("split_out_pieces", c_int)]
 
 
 TILE_STREAMK = 257
@@ -102,11 +102,14 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
                a_kmajor=False, b_kmajor=False, out_f32=False, bias=None, gelu=False, residual=None, out_pre=None,
                dgelu_aux=None, alpha: Optional[float] = None, dropout_p: float = 0.0, seed: int = 0, split_k: int = 1,
                accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None, tile: int = 0,
-               ldaux=None, pre_dgelu: bool = False, mul_aux=None, colscale=None, residual_f32=None):
+               ldaux=None, pre_dgelu: bool = False, mul_aux=None, colscale=None, residual_f32=None, split_out=None):
     """Fills one aptai_gemm_desc in place; returns (out, workspace) - the caller keeps them alive across the launch."""
     _dev(a, b, out, bias, residual, out_pre, dgelu_aux, mul_aux)
     if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        if split_out:          # exact-index mode: fp32 result written as `split_out` bf16 pieces (EPI_SPLIT_OUT); ldc in bf16 elements
+            out = torch.empty((M, N * int(split_out)), device=a.device, dtype=torch.bfloat16)
+        else:
+            out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     d.A, d.lda = a.data_ptr(), lda if lda is not None else (a.stride(0))
     d.B, d.ldb = b.data_ptr(), ldb if ldb is not None else (b.stride(0))
     d.C, d.ldc = out.data_ptr(), ldc if ldc is not None else out.stride(0)
@@ -141,6 +144,11 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
     if dropout_p > 0:
         flags |= EPI_DROPOUT
         d.dropout_p, d.seed = dropout_p, seed
+    if split_out:
+        if out.dtype != torch.bfloat16 or not out_f32:
+            raise ValueError("split_out writes bf16 pieces from an out_f32 launch")
+        flags |= EPI_SPLIT_OUT
+        d.split_out_pieces = int(split_out)
     d.flags = flags
     d.split_k, d.accumulate = split_k, int(accumulate)
     d.tile = tile if tile else _AUTO_TILE
@@ -343,8 +351,12 @@ def conv0_fwd_f32(audio, weight, bias, gamma, beta, mode, out32, T_real, T_alloc
 
 
 def gemm_split(a_s: torch.Tensor, w_s: torch.Tensor, M: int, N: int, K: int, pieces: int, *, lda=None, bias=None, residual_f32=None,
-               out=None, ldc=None) -> torch.Tensor:
-    """fp32 C[M][N] = A . W^T (+ bias) (+ fp32 residual) from split operands (split_f32): one NT launch of K' = pieces * K."""
+               out=None, ldc=None, split_out: bool = False, gelu: bool = False) -> torch.Tensor:
+    """fp32 C[M][N] = A . W^T (+ bias) (+ fp32 residual) from split operands (split_f32): one NT launch of K' = pieces * K.
+    split_out: the result (after the erf GELU when `gelu`) is returned as split bf16 pieces [M][pieces N] instead - the next product's A."""
+    if split_out:
+        return gemm(a_s, w_s, M, N, K * pieces, lda=(lda * pieces if lda is not None else None), out_f32=True, bias=bias, gelu=gelu,
+                    residual_f32=residual_f32, out=out, ldc=ldc, tile=128, split_out=pieces)
     # fp32-output launches name their tile (include/aptai_hip.h); whole rounds of 256 x 256 tiles where the output has them (the conv
     # stack's [B x 16384 ...] x 512 outputs: 3 x the bf16 work at K' = 3 K is the longest loop of the build), 128-row tiles elsewhere
     t256 = -(-M // 256) * -(-N // 256)

@@ -899,7 +899,11 @@ class Wav2Vec2Model(nn.Module):
             G = cfg.num_conv_pos_embedding_groups
             Hh, Cg, Kw = v.shape
             wn = v * (g0 / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt())
-            w.posconv = wn.view(G, Cg, Cg, Kw).permute(0, 1, 3, 2).reshape(G, Cg, Kw * Cg).contiguous()
+            # split form (round 4): the input channels of a group padded 48 -> 64, so that one FRAME of a group is exactly one K-tile of
+            # the split layout and the Toeplitz rows of the implicit GEMM stay contiguous ([tap][64 channels] = tap * 64 + c)
+            w64 = torch.zeros((G, Cg, Kw, 64), device=wn.device, dtype=torch.float32)
+            w64[..., :Cg] = wn.view(G, Cg, Cg, Kw).permute(0, 1, 3, 2)
+            w.posconv = ops.split_f32(w64.view(G * Cg, Kw * 64), P, weight_side=True)                 # [G Cg][P Kw 64]
             for i in range(len(self.encoder.layers)):
                 p = [t.detach() for t in self._layer_params(i)]
                 w.layers.append(SimpleNamespace(
@@ -932,10 +936,11 @@ class Wav2Vec2Model(nn.Module):
         ps = ops.softmax_split_f32(s32, lens_i32, B, heads, Tp, P)              # [B heads Tp][P Tp]: softmax + split in one pass
         vt = qkv32[:, 2 * H:].reshape(B, Tp, heads, d).permute(0, 2, 3, 1).contiguous()            # [B][heads][d][Tp] fp32
         vts = ops.split_f32(vt.view(B * heads * d, Tp), P, weight_side=True)    # [B heads d][P Tp]
-        ctx = torch.empty((M, H), device=dev, dtype=torch.float32)
-        ops.gemm(ps, vts, Tp, d, P * Tp, lda=P * Tp, ldb=P * Tp, out=ctx, ldc=H, out_f32=True, tile=128,
-                 batch=dict(outer=B, inner=heads, a=(heads * Tp * P * Tp, Tp * P * Tp), b=(heads * d * P * Tp, d * P * Tp), c=(Tp * H, d)))
-        return ctx
+        # the context leaves as the out-projection's split A operand (head h = K-tile h of the split layout: column block h * 64 P)
+        ctx_s = torch.empty((M, P * H), device=dev, dtype=torch.bfloat16)
+        ops.gemm(ps, vts, Tp, d, P * Tp, lda=P * Tp, ldb=P * Tp, out=ctx_s, ldc=P * H, out_f32=True, tile=128, split_out=P,
+                 batch=dict(outer=B, inner=heads, a=(heads * Tp * P * Tp, Tp * P * Tp), b=(heads * d * P * Tp, d * P * Tp), c=(Tp * P * H, P * d)))
+        return ctx_s
 
     def _forward_exact(self, audio, g, lens_i32, P, output_hidden_states):
         """The whole encoder in eval mode at fp32-class accuracy (set_encoder_precision("f32x3" | "f32x6")).  Returns
@@ -976,14 +981,20 @@ class Wav2Vec2Model(nn.Module):
         ops.bias_act_res_f32(h0, lens_i32=lens_i32, rows_per_b=g.Tp, out=h0)
         G, Kw = cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
         Cg, pad = H // G, Kw // 2
+        if Cg > 64 or Cg % 8:
+            raise NotImplementedError("the exact positional conv is built for at most 64 channels per group (a multiple of 8)")
         rows_p = g.Tp + 2 * pad
-        xg = torch.zeros((G, g.B, rows_p, Cg), device=dev, dtype=torch.float32)
-        xg[:, :, pad:pad + g.Tp].copy_(h0.view(g.B, g.Tp, G, Cg).permute(2, 0, 1, 3))
+        # grouped Conv1d(k = 128, 'same') as ONE batched split-operand NT launch over (group, utterance): row t of group grp is the Kw
+        # frames t .. t + Kw - 1 of the zero-padded sequence, 64 (48 real) channels each - lda = one frame.  (Round 3 ran it as 16
+        # batched calls on the fp32 matrix instruction: 2.4 ms of the exact-mode step.)
+        xg = torch.zeros((G, g.B, rows_p, 64), device=dev, dtype=torch.float32)
+        xg[:, :, pad:pad + g.Tp, :Cg].copy_(h0.view(g.B, g.Tp, G, Cg).permute(2, 0, 1, 3))
+        xs = ops.split_f32(xg.view(G * g.B * rows_p, 64), P)                                           # [G B rows_p][P 64]
         pc = self.encoder.pos_conv_embed.conv
         conv = torch.empty((M, H), device=dev, dtype=torch.float32)
-        for grp in range(G):
-            ops.sgemm(xg[grp], Cg, 1, W.posconv[grp], 1, Kw * Cg, g.Tp, Cg, Kw * Cg, out=conv[:, grp * Cg:], ldc=H,
-                      bias=pc.bias[grp * Cg:(grp + 1) * Cg], batch=g.B, bsa=rows_p * Cg, bsb=0, bsc=g.Tp * H)
+        KP = P * Kw * 64
+        ops.gemm(xs, W.posconv, g.Tp, Cg, KP, lda=P * 64, ldb=KP, out=conv, ldc=H, out_f32=True, bias=pc.bias, tile=128,
+                 batch=dict(outer=G, inner=g.B, a=(g.B * rows_p * P * 64, rows_p * P * 64), b=(Cg * KP, 0), c=(Cg, g.Tp * H), bias=(Cg, 0)))
         h = ops.bias_act_res_f32(conv, gelu=True, res=h0)
         if not cfg.do_stable_layer_norm:
             _, h = ops.layernorm_fwd_f32in(h, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias, eps, want_bf16=False)
@@ -999,15 +1010,16 @@ class Wav2Vec2Model(nn.Module):
                 a_in = h
             qkv = ops.gemm_split(ops.split_f32(a_in, P), w.wqkv, M, 3 * H, H, P, bias=w.bqkv)
             ctx = self._exact_attention(qkv, lens_i32, g, P)
-            s1 = ops.gemm_split(ops.split_f32(ctx, P), w.wo, M, H, H, P, bias=w.bo, residual_f32=h)
+            s1 = ops.gemm_split(ctx, w.wo, M, H, H, P, bias=w.bo, residual_f32=h)          # ctx: already split
             if cfg.do_stable_layer_norm:
                 _, f_in = ops.layernorm_fwd_f32in(s1, ln2.weight, ln2.bias, eps, want_bf16=False)
                 res2 = s1
             else:
                 _, f_in = ops.layernorm_fwd_f32in(s1, ln1.weight, ln1.bias, eps, want_bf16=False)
                 res2 = f_in
-            u = ops.gemm_split(ops.split_f32(f_in, P), w.w1, M, I, H, P, bias=w.b1)
-            s2 = ops.gemm_split(ops.split_f32(u, P, gelu=True), w.w2, M, H, I, P, bias=w.b2, residual_f32=res2)
+            # FFN1's result leaves its GEMM already GELU'd and split (EPI_SPLIT_OUT): 100 MB of fp32 and a split pass less per layer
+            us = ops.gemm_split(ops.split_f32(f_in, P), w.w1, M, I, H, P, bias=w.b1, split_out=True, gelu=True)
+            s2 = ops.gemm_split(us, w.w2, M, H, I, P, bias=w.b2, residual_f32=res2)
             if cfg.do_stable_layer_norm:
                 h = s2
             else:

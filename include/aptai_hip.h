@@ -62,8 +62,12 @@ enum {
     APTAI_EPI_ALPHA = 32,
     APTAI_EPI_PRE_DGELU = 64, /* with EPI_GELU: out_pre receives dropmask/(1-p) * gelu'(pre-activation) instead of the pre-activation */
     APTAI_EPI_MUL_AUX = 128,  /* *= aux[m*ldaux+n] (bf16): the backward partner of EPI_PRE_DGELU */
-    APTAI_EPI_RESIDUAL_F32 = 256 /* fp32 output only (tile 64 / 128 / 192): += residual[m*ldr+n] read as FP32 - the residual stream of the
-                                  * inference-only encoder kept in fp32 (HF:594-601: hidden_states = attn_residual + hidden_states) */
+    APTAI_EPI_RESIDUAL_F32 = 256, /* fp32 output only (tile 64 / 128 / 192): += residual[m*ldr+n] read as FP32 - the residual stream of the
+                                   * inference-only encoder kept in fp32 (HF:594-601: hidden_states = attn_residual + hidden_states) */
+    APTAI_EPI_SPLIT_OUT = 512     /* out_f32 launches on tile 128 only (exact-index mode): the fp32 result [-> erf GELU with EPI_GELU] leaves as
+                                   * `split_out_pieces` bf16 pieces in the activation-side layout of aptai_split_f32, [m][N/64][piece][64],
+                                   * C = bf16*, ldc (and the C batch strides) in bf16 elements, ldc >= pieces * N: the next split-operand
+                                   * GEMM's A operand, written once instead of an fp32 store, a re-read and a split pass */
 };
 
 typedef struct {
@@ -96,6 +100,7 @@ typedef struct {
                                        fp32 partial-tile slabs + ready flags (self-cleaning) + status word of the stream-K kernel.  With it the
                                        auto rule may pick the stream-K form; without it tile 257 is refused and auto never picks it */
     int64_t sk_workspace_bytes;
+    int split_out_pieces;           /* with APTAI_EPI_SPLIT_OUT: 3 or 6 */
 } aptai_gemm_desc;
 
 int aptai_gemm_bf16(const aptai_gemm_desc* desc, void* stream);

@@ -167,3 +167,35 @@ def test_exact_mode_large_30s_alignment_equal_on_every_frame(prec, max_dev):
           + "".join(f"; frame {i}: oracle margin {top2[i, 1] - top2[i, 0]:.2e}" for i in diff[:8]))
     assert dev <= max_dev
     assert diff.size == 0
+
+
+@pytest.mark.parametrize("P", [3, 6])
+def test_split_out_epilogue_equals_gemm_then_split(P):
+    """APTAI_EPI_SPLIT_OUT (round 4): a split-operand GEMM whose fp32 result [-> erf GELU] leaves as the NEXT product's split A operand must
+    equal the two-pass form it replaces (fp32 store, aptai_split_f32) bit for bit - plain, with bias + GELU (FFN1), and batched over
+    (utterance, head) with the head's 64 columns as one K-tile of the output layout (attention context)."""
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 300, 256, 128
+    a32, w32 = torch.randn(M, K, generator=g).cuda(), (torch.randn(N, K, generator=g) * 0.2).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    a_s, w_s = ops.split_f32(a32, P), ops.split_f32(w32, P, weight_side=True)
+    for gelu in (False, True):
+        two = ops.split_f32(ops.gemm_split(a_s, w_s, M, N, K, P, bias=bias), P, gelu=gelu)
+        one = ops.gemm_split(a_s, w_s, M, N, K, P, bias=bias, split_out=True, gelu=gelu)
+        assert one.dtype == torch.bfloat16 and one.shape == (M, P * N)
+        assert torch.equal(one.view(torch.int16), two.view(torch.int16)), gelu
+    # batched: B x heads problems of [T][64] outputs written into [B T][P heads 64]
+    B, heads, T, d = 2, 3, 128, 64
+    p32 = torch.rand(B * heads * T, T, generator=g).cuda()
+    vt32 = torch.randn(B * heads * d, T, generator=g).cuda()
+    ps, vts = ops.split_f32(p32, P), ops.split_f32(vt32, P, weight_side=True)
+    H = heads * d
+    batch = lambda cs: dict(outer=B, inner=heads, a=(heads * T * P * T, T * P * T), b=(heads * d * P * T, d * P * T), c=cs)
+    ctx32 = torch.empty(B * T, H, device="cuda")
+    ops.gemm(ps, vts, T, d, P * T, lda=P * T, ldb=P * T, out=ctx32, ldc=H, out_f32=True, tile=128, batch=batch((T * H, d)))
+    ctx_s = torch.empty(B * T, P * H, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(ps, vts, T, d, P * T, lda=P * T, ldb=P * T, out=ctx_s, ldc=P * H, out_f32=True, tile=128, split_out=P, batch=batch((T * P * H, P * d)))
+    assert torch.equal(ctx_s.view(torch.int16), ops.split_f32(ctx32, P).view(torch.int16))
+    with pytest.raises(Exception):
+        ops.gemm(ps, vts, T, d, P * T, lda=P * T, ldb=P * T, out=ctx_s, ldc=P * H, out_f32=True, tile=256, split_out=P)
