@@ -361,6 +361,9 @@ def gemm_split(a_s: torch.Tensor, w_s: torch.Tensor, M: int, N: int, K: int, pie
     # stack's [B x 16384 ...] x 512 outputs: 3 x the bf16 work at K' = 3 K is the longest loop of the build), 128-row tiles elsewhere
     t256 = -(-M // 256) * -(-N // 256)
     tile = 256 if (M >= 256 and N >= 256 and t256 >= 1024) else 128
+    # one round of full 128 x 192 tiles (the [8192] x 768 outputs of out-proj / FFN2 at K' = 3 K): the 3-stage-ring kernel, as on the bf16 path
+    if tile == 128 and M % 128 == 0 and N % 192 == 0 and 192 < (M // 128) * (N // 192) <= 256:
+        tile = 192
     return gemm(a_s, w_s, M, N, K * pieces, lda=(lda * pieces if lda is not None else None), out_f32=True, bias=bias,
                 residual_f32=residual_f32, out=out, ldc=ldc, tile=tile)
 

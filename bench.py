@@ -34,7 +34,7 @@ FWD_GF = {  # algorithmic GFLOP / utterance, forward (multiply-a
     ("base", 10.0): dict(conv=49.08, enc=99.05), ("large", 10.0): dict(conv=49.08, enc=334.76),
     ("base", 4.0): dict(conv=19.63, enc=37.30), ("large", 30.0): dict(conv=147.25, enc=1152.98),
 }
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def parse():
