@@ -153,7 +153,7 @@ __device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d
 
 // ---- round 3: the same tile and the same MFMA loop fed by LDS-DMA (global_load_lds, 16 B / lane) into an unpadded, XOR-swizzled
 // LDS image, two stages, one barrier per K-tile, and a coalesced epilogue through LDS.  Why it matters here: the bf16 GEMMs of this
-// library are bound by operand delivery (~50 KB/us per CU); a K-tile of 128 fp8 elements is the 32 KB the bf16
+// library are bound by operand delivery (~50 KB/us per CU, DESIGN.md sections 8 and 9); a K-tile of 128 fp8 elements is the 32 KB the bf16
 // 128-tile stages for 64 elements, and the scaled MFMA retires it in the same cycles - so the same delivery rate carries twice the MACs.
 // LDS image of an operand tile: row r = 128 bytes = 8 chunks of 16 B, chunk c at slot c ^ (r & 7) (the 32 rows of a fragment read
 // cover the 8 slots evenly); the hardware writes lane-linear, so thread t of instruction `it` FETCHES chunk ((t & 7) ^ (row & 7)) of

@@ -152,7 +152,7 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
     d.flags = flags
     d.split_k, d.accumulate = split_k, int(accumulate)
     d.tile = tile if tile else _AUTO_TILE
-    if tile == TILE_STREAMK:          # opt-in only: measured slower than the tile rule's choice on every hot-path shape (DESIGN section 8)
+    if tile == TILE_STREAMK:          # opt-in only: measured slower than the tile rule's choice on every hot-path shape (DESIGN section 9)
         ws_sk = _sk_workspace(a.device)
         d.sk_workspace, d.sk_workspace_bytes = ws_sk.data_ptr(), ws_sk.numel()
     if colscale is not None:       # (n_cols, factor): output columns [0, n_cols) *= factor after alpha / bias

@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of aptai_amd.optim.Adam")
     ap.add_argument("--host-batch", action="store_true", help="hand the step a pinned HOST batch every iteration (PCIe-inclusive rate; "
-                    "never the headline value: DESIGN.md section 8)")
+                    "never the headline value: DESIGN.md section 11)")
     ap.add_argument("--encoder-precision", default="bf16_f32res", choices=["bf16_f32res", "bf16", "mxfp8", "f32x3", "f32x6"],
                     help="force workload: precision of the frozen encoder (mxfp8 = BASELINE configs[4]; bf16_f32res = bf16 GEMMs with an fp32 residual stream)")
     ap.add_argument("--plan-gpus", type=int, default=8, help="world size the JSON line's collective_plan is written for when the run itself is "
