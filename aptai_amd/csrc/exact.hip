@@ -184,12 +184,13 @@ struct Conv0xArgs {
     const float* w; const float* bias; const float* gamma; const float* beta; const float* stats;
     float* out; int T_real, T_alloc, mode;
     float eps;
+    bf16_t* out_s; int pieces;      // != null: the result leaves as split bf16 pieces [frame][512 / 64][piece][64] instead of fp32
 };
 __global__ __launch_bounds__(256) void conv0_exact_kernel(Conv0xArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const float* xb = a.audio + (long)b * a.S;
-    float* ob = a.out + (long)b * a.T_alloc * C0;
+    float* ob = a.out + (long)b * a.T_alloc * C0;      // (unused when the result leaves split)
     // taps, bias and the affine of this lane's 8 channels live in registers for the whole launch (round 4: the first form re-loaded the
     // 80 taps and the per-channel parameters from memory for every frame: 2.5 ms per call at 16 x 10 s, 8 % of the exact-mode step)
     float w[8][KW], bs[8], sc[8], sh[8];
@@ -239,6 +240,19 @@ __global__ __launch_bounds__(256) void conv0_exact_kernel(Conv0xArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = gelu_exact((v[j] - mu) * rs * gm[j] + bt[j]);
             }
+        }
+        if (a.out_s != nullptr) {                            // lane * 8 .. + 7 lie inside one 64-channel K-tile of the split layout
+            float h[8], md[8], lw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split3(o[j], h[j], md[j], lw[j]);
+            const int c0 = lane * 8;
+            bf16_t* dst = a.out_s + ((long)b * a.T_alloc + t) * (C0 * a.pieces) + (long)(c0 >> 6) * (64 * a.pieces) + (c0 & 63);
+            auto put = [&](int piece, const float (&q)[8]) {
+                *(u32x4*)(dst + piece * 64) = (u32x4){pack2bf(q[0], q[1]), pack2bf(q[2], q[3]), pack2bf(q[4], q[5]), pack2bf(q[6], q[7])};
+            };
+            put(0, h); put(1, h); put(2, md);
+            if (a.pieces == 6) { put(3, md); put(4, h); put(5, lw); }
+            continue;
         }
         float* dst = ob + (long)t * C0 + lane * 8;
         *(f32x4*)dst = (f32x4){o[0], o[1], o[2], o[3]};
@@ -313,7 +327,22 @@ extern "C" int aptai_conv0_fwd_f32(const float* audio, int64_t B, int64_t S, con
     APTAI_REQUIRE(mode == 0 || mode == 1, "aptai_conv0_fwd_f32: mode must be 0 (group) or 1 (layer)");
     APTAI_REQUIRE(mode == 1 || stats != nullptr, "aptai_conv0_fwd_f32: group mode needs the (mean, rstd) block of aptai_conv0_fwd");
     APTAI_REQUIRE(T_real >= 1 && T_alloc >= T_real && (T_real - 1) * STRIDE + KW <= S, "aptai_conv0_fwd_f32: frames exceed the waveform");
-    Conv0xArgs a{audio, (long)S, weight, bias, gamma, beta, stats, out, (int)T_real, (int)T_alloc, mode, eps};
+    Conv0xArgs a{audio, (long)S, weight, bias, gamma, beta, stats, out, (int)T_real, (int)T_alloc, mode, eps, nullptr, 0};
+    const unsigned bx = (unsigned)((T_alloc + 3) / 4 < 2048 ? (T_alloc + 3) / 4 : 2048);
+    APTAI_LAUNCH(conv0_exact_kernel, dim3(bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+    APTAI_CHECK_LAUNCH("conv0_exact_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_conv0_fwd_split(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias, const float* gamma,
+                                     const float* beta, int mode, float eps, void* out_split, int pieces, int64_t T_real, int64_t T_alloc,
+                                     const float* stats, void* stream) {
+    APTAI_REQUIRE(audio && weight && gamma && beta && out_split, "aptai_conv0_fwd_split: null pointer");
+    APTAI_REQUIRE(mode == 0 || mode == 1, "aptai_conv0_fwd_split: mode must be 0 (group) or 1 (layer)");
+    APTAI_REQUIRE(mode == 1 || stats != nullptr, "aptai_conv0_fwd_split: group mode needs the (mean, rstd) block of aptai_conv0_fwd");
+    APTAI_REQUIRE(pieces == 3 || pieces == 6, "aptai_conv0_fwd_split: pieces must be 3 or 6");
+    APTAI_REQUIRE(T_real >= 1 && T_alloc >= T_real && (T_real - 1) * STRIDE + KW <= S, "aptai_conv0_fwd_split: frames exceed the waveform");
+    Conv0xArgs a{audio, (long)S, weight, bias, gamma, beta, stats, nullptr, (int)T_real, (int)T_alloc, mode, eps, (bf16_t*)out_split, pieces};
     const unsigned bx = (unsigned)((T_alloc + 3) / 4 < 2048 ? (T_alloc + 3) / 4 : 2048);
     APTAI_LAUNCH(conv0_exact_kernel, dim3(bx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
     APTAI_CHECK_LAUNCH("conv0_exact_kernel");

@@ -414,18 +414,7 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
                     for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
                 }
                 if (flags & APTAI_EPI_SPLIT_OUT) {               // exact-index mode: the result leaves as the next GEMM's split A operand
-                    float h[8], md[8], lw[8];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        if (flags & APTAI_EPI_GELU) v[r] = gelu_exact(v[r]);
-                        split3(v[r], h[r], md[r], lw[r]);
-                    }
-                    bf16_t* dst = (bf16_t*)g.C + (long)m * g.ldc + (long)(n >> 6) * (64 * g.split_pieces) + (n & 63);
-                    auto put = [&](int piece, const float (&q)[8]) {
-                        *(u32x4*)(dst + piece * 64) = (u32x4){pack2bf(q[0], q[1]), pack2bf(q[2], q[3]), pack2bf(q[4], q[5]), pack2bf(q[6], q[7])};
-                    };
-                    put(0, h); put(1, h); put(2, md);            // activation side: hi hi lo | hi hi mid mid hi low
-                    if (g.split_pieces == 6) { put(3, md); put(4, h); put(5, lw); }
+                    split_out_store(g, flags, v, (long)m, n);
                     return;
                 }
                 float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
@@ -786,6 +775,7 @@ __device__ __forceinline__ void gemm256_epilogue_body(const GemmArgs& g, char* s
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
                     }
+                    if (flags & APTAI_EPI_SPLIT_OUT) { split_out_store(g, flags, v, (long)m, n); continue; }
                     float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
                     *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
                     *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -837,7 +827,7 @@ __global__ __launch_bounds__(T2_THREADS, 2) void gemm256_kernel(GemmArgs g) {
         g.A += bo * g.sA[0] + bi * g.sA[1];
         g.B += bo * g.sB[0] + bi * g.sB[1];
         const long co = bo * g.sC[0] + bi * g.sC[1];
-        g.C = OUT_F32 ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
+        g.C = (OUT_F32 && !(g.flags & APTAI_EPI_SPLIT_OUT)) ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
         if (g.out_pre) g.out_pre += co;
         if (g.bias) g.bias += bo * g.sBias[0] + bi * g.sBias[1];
         if (g.residual) g.residual += bo * g.sR[0] + bi * g.sR[1];
@@ -1157,7 +1147,7 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
         g.A += bo * g.sA[0] + bi * g.sA[1];
         g.B += bo * g.sB[0] + bi * g.sB[1];
         const long co = bo * g.sC[0] + bi * g.sC[1];
-        g.C = OUT_F32 ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
+        g.C = (OUT_F32 && !(g.flags & APTAI_EPI_SPLIT_OUT)) ? (void*)((float*)g.C + co) : (void*)((bf16_t*)g.C + co);
         if (g.out_pre) g.out_pre += co;
         if (g.bias) g.bias += bo * g.sBias[0] + bi * g.sBias[1];
         if (g.residual) g.residual += bo * g.sR[0] + bi * g.sR[1];
@@ -1409,6 +1399,7 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
     #pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
                 }
+                if (flags & APTAI_EPI_SPLIT_OUT) { split_out_store(g, flags, v, (long)m, n); continue; }
                 float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
                 *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
                 *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -1471,9 +1462,9 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     if (d->flags & APTAI_EPI_PRE_DGELU) APTAI_REQUIRE(d->out_pre != nullptr && (d->flags & APTAI_EPI_GELU), "aptai_gemm_bf16: EPI_PRE_DGELU needs EPI_GELU and out_pre");
 
     if (d->flags & APTAI_EPI_SPLIT_OUT)
-        APTAI_REQUIRE(d->out_f32 && d->tile == 128 && !d->a_kmajor && d->split_k <= 1 && !d->accumulate && (d->split_out_pieces == 3 || d->split_out_pieces == 6) &&
+        APTAI_REQUIRE(d->out_f32 && (d->tile == 128 || d->tile == 192 || d->tile == 256) && !d->a_kmajor && d->split_k <= 1 && !d->accumulate && (d->split_out_pieces == 3 || d->split_out_pieces == 6) &&
                       d->ldc >= d->split_out_pieces * d->N && d->N % 8 == 0,
-                      "aptai_gemm_bf16: EPI_SPLIT_OUT needs out_f32, tile 128, 3 or 6 pieces and ldc >= pieces * N (bf16 elements)");
+                      "aptai_gemm_bf16: EPI_SPLIT_OUT needs out_f32, tile 128 / 192 / 256, 3 or 6 pieces and ldc >= pieces * N (bf16 elements)");
     APTAI_REQUIRE(d->colscale_n >= 0 && d->colscale_n % 8 == 0 && d->colscale_n <= d->N && (d->colscale_n == 0 || !d->out_f32),
                   "aptai_gemm_bf16: colscale_n must be a multiple of 8 within N, bf16 output only");
     memset(&g, 0, sizeof(g));

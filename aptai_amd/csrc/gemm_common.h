@@ -287,6 +287,23 @@ __device__ __forceinline__ void raster2d(int bid, int tiles_m, int tiles_n, int 
     tile_n = r / rows;
 }
 
+// APTAI_EPI_SPLIT_OUT (exact-index mode): 8 consecutive fp32 results of output row m leave as `split_pieces` bf16 pieces in the
+// activation-side layout of aptai_split_f32 ([m][N/64][piece][64]), after the erf GELU when the launch carries APTAI_EPI_GELU.
+__device__ __forceinline__ void split_out_store(const GemmArgs& g, const int flags, float (&v)[8], const long m, const int n) {
+    float h[8], md[8], lw[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (flags & APTAI_EPI_GELU) v[r] = gelu_exact(v[r]);
+        split3(v[r], h[r], md[r], lw[r]);
+    }
+    bf16_t* dst = (bf16_t*)g.C + m * g.ldc + (long)(n >> 6) * (64 * g.split_pieces) + (n & 63);
+    auto put = [&](int piece, const float (&q)[8]) {
+        *(u32x4*)(dst + piece * 64) = (u32x4){pack2bf(q[0], q[1]), pack2bf(q[2], q[3]), pack2bf(q[4], q[5]), pack2bf(q[6], q[7])};
+    };
+    put(0, h); put(1, h); put(2, md);                    // activation side: hi hi lo | hi hi mid mid hi low
+    if (g.split_pieces == 6) { put(3, md); put(4, h); put(5, lw); }
+}
+
 // 256 x 192 tile kernel (gemm_t4.hip): bf16 output, K-contiguous A, B K-contiguous or K-major; no batching / split-K
 int launch_gemm_t4(GemmArgs g, bool b_km, hipStream_t stream);
 

@@ -334,6 +334,15 @@ def softmax_rows_f32(s32, lens_i32, B, heads, Tp):
     return s32
 
 
+def conv0_fwd_split(audio, weight, bias, gamma, beta, mode, out_split, pieces, T_real, T_alloc, stats, eps=1e-5):
+    """The exact mode's first conv layer with its (already activated) result written as split bf16 pieces (aptai_conv0_fwd_split)."""
+    _dev(audio, weight, bias, gamma, beta, out_split, stats)
+    B, S = audio.shape
+    _lib.call("aptai_conv0_fwd_split", audio.data_ptr(), B, S, weight.data_ptr(), _ptr(bias), gamma.data_ptr(), beta.data_ptr(), mode, eps,
+              out_split.data_ptr(), pieces, T_real, T_alloc, _ptr(stats), _stream())
+    return out_split
+
+
 def softmax_split_f32(s32, lens_i32, B, heads, Tp, pieces):
     """Masked softmax of the fp32 scores [B][heads][Tp][Tp] written as split bf16 pieces [B heads Tp][pieces Tp] (aptai_softmax_split_f32)."""
     _dev(s32, lens_i32)
@@ -354,9 +363,6 @@ def gemm_split(a_s: torch.Tensor, w_s: torch.Tensor, M: int, N: int, K: int, pie
                out=None, ldc=None, split_out: bool = False, gelu: bool = False) -> torch.Tensor:
     """fp32 C[M][N] = A . W^T (+ bias) (+ fp32 residual) from split operands (split_f32): one NT launch of K' = pieces * K.
     split_out: the result (after the erf GELU when `gelu`) is returned as split bf16 pieces [M][pieces N] instead - the next product's A."""
-    if split_out:
-        return gemm(a_s, w_s, M, N, K * pieces, lda=(lda * pieces if lda is not None else None), out_f32=True, bias=bias, gelu=gelu,
-                    residual_f32=residual_f32, out=out, ldc=ldc, tile=128, split_out=pieces)
     # fp32-output launches name their tile (include/aptai_hip.h); whole rounds of 256 x 256 tiles where the output has them (the conv
     # stack's [B x 16384 ...] x 512 outputs: 3 x the bf16 work at K' = 3 K is the longest loop of the build), 128-row tiles elsewhere
     t256 = -(-M // 256) * -(-N // 256)
@@ -364,8 +370,8 @@ def gemm_split(a_s: torch.Tensor, w_s: torch.Tensor, M: int, N: int, K: int, pie
     # one round of full 128 x 192 tiles (the [8192] x 768 outputs of out-proj / FFN2 at K' = 3 K): the 3-stage-ring kernel, as on the bf16 path
     if tile == 128 and M % 128 == 0 and N % 192 == 0 and 192 < (M // 128) * (N // 192) <= 256:
         tile = 192
-    return gemm(a_s, w_s, M, N, K * pieces, lda=(lda * pieces if lda is not None else None), out_f32=True, bias=bias,
-                residual_f32=residual_f32, out=out, ldc=ldc, tile=tile)
+    return gemm(a_s, w_s, M, N, K * pieces, lda=(lda * pieces if lda is not None else None), out_f32=True, bias=bias, gelu=(gelu and split_out),
+                residual_f32=residual_f32, out=out, ldc=ldc, tile=tile, split_out=(pieces if split_out else None))
 
 
 # ----------------------------------------------------------------------------- LayerNorm

@@ -959,20 +959,47 @@ class Wav2Vec2Model(nn.Module):
             scratch = self._scratch(("conv", 0, g.B * g.alloc[0] + 8), (g.B * g.alloc[0] + 8) * C, dev).view(-1, C)
             stats = ops.conv0_fwd(audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight,
                                   l0.layer_norm.bias, 0, scratch, g.Tl[0], g.alloc[0], want_stats=True)
-        buf = torch.zeros((g.B * g.alloc[0] + 8, C), device=dev, dtype=torch.float32)
-        ops.conv0_fwd_f32(audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight, l0.layer_norm.bias,
-                          1 if layer_mode else 0, buf, g.Tl[0], g.alloc[0], stats)
-        pending_gelu = False                                 # base: GELU of layer i is applied when layer i+1 splits its input
-        for i in range(1, len(cl)):
-            k, s = cfg.conv_kernel[i], cfg.conv_stride[i]
-            Mi = g.B * g.alloc[i]
-            xs = ops.split_f32(buf, P, gelu=pending_gelu)
-            out = torch.zeros((Mi + 8, C), device=dev, dtype=torch.float32)
-            ops.gemm_split(xs, W.conv[i - 1], Mi, C, k * C, P, lda=s * C, bias=cl[i].conv.bias if cfg.conv_bias else None, out=out, ldc=C)
-            if layer_mode:
+        if layer_mode:
+            # wav2vec2-large: a LayerNorm sits between the conv layers, so every layer's fp32 output is stored, normalised and split
+            buf = torch.empty((g.B * g.alloc[0] + 8, C), device=dev, dtype=torch.float32)
+            buf[g.B * g.alloc[0]:].zero_()
+            ops.conv0_fwd_f32(audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight, l0.layer_norm.bias,
+                              1, buf, g.Tl[0], g.alloc[0], stats)
+            pending_gelu = False
+            for i in range(1, len(cl)):
+                k, s = cfg.conv_kernel[i], cfg.conv_stride[i]
+                Mi = g.B * g.alloc[i]
+                xs = ops.split_f32(buf, P, gelu=pending_gelu)
+                out = torch.empty((Mi + 8, C), device=dev, dtype=torch.float32)
+                out[Mi:].zero_()
+                ops.gemm_split(xs, W.conv[i - 1], Mi, C, k * C, P, lda=s * C, bias=cl[i].conv.bias if cfg.conv_bias else None, out=out, ldc=C)
                 _, y32 = ops.layernorm_fwd_f32in(out[:Mi], cl[i].layer_norm.weight, cl[i].layer_norm.bias, 1e-5, want_bf16=False)
                 out[:Mi].copy_(y32)
-            buf, pending_gelu = out, True
+                buf, pending_gelu = out, True
+        else:
+            # wav2vec2-base (round 4): no fp32 intermediate between the conv layers at all - the first layer writes its activated output as
+            # split pieces (aptai_conv0_fwd_split), layers 1..5 leave their GEMMs GELU'd and split (APTAI_EPI_SPLIT_OUT | APTAI_EPI_GELU),
+            # only the last layer's output is fp32 (it feeds the feature projection's LayerNorm).  The 8 slack rows the overlapping-row
+            # view of the next layer can read are zeroed; frames beyond an utterance are padded frames like everywhere else.
+            M0 = g.B * g.alloc[0]
+            xs = torch.empty((M0 + 8, P * C), device=dev, dtype=torch.bfloat16)
+            xs[M0:].zero_()
+            ops.conv0_fwd_split(audio, l0.conv.weight, l0.conv.bias if cfg.conv_bias else None, l0.layer_norm.weight, l0.layer_norm.bias,
+                                0, xs, P, g.Tl[0], g.alloc[0], stats)
+            for i in range(1, len(cl)):
+                k, s = cfg.conv_kernel[i], cfg.conv_stride[i]
+                Mi = g.B * g.alloc[i]
+                last = i == len(cl) - 1
+                bias_i = cl[i].conv.bias if cfg.conv_bias else None
+                if last:
+                    buf = torch.empty((Mi + 8, C), device=dev, dtype=torch.float32)
+                    buf[Mi:].zero_()
+                    ops.gemm_split(xs, W.conv[i - 1], Mi, C, k * C, P, lda=s * C, bias=bias_i, out=buf, ldc=C)
+                else:
+                    nxt = torch.empty((Mi + 8, P * C), device=dev, dtype=torch.bfloat16)
+                    nxt[Mi:].zero_()
+                    ops.gemm_split(xs, W.conv[i - 1], Mi, C, k * C, P, lda=s * C, bias=bias_i, out=nxt, ldc=P * C, split_out=True, gelu=True)
+                    xs = nxt
         feats = ops.bias_act_res_f32(buf[:M], gelu=True)                                               # [M][512] fp32
         # ---- feature projection, padded-frame zeroing, positional conv (HF:422-434, 678-681, 326-379)
         fp = self.feature_projection

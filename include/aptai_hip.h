@@ -64,7 +64,7 @@ enum {
     APTAI_EPI_MUL_AUX = 128,  /* *= aux[m*ldaux+n] (bf16): the backward partner of EPI_PRE_DGELU */
     APTAI_EPI_RESIDUAL_F32 = 256, /* fp32 output only (tile 64 / 128 / 192): += residual[m*ldr+n] read as FP32 - the residual stream of the
                                    * inference-only encoder kept in fp32 (HF:594-601: hidden_states = attn_residual + hidden_states) */
-    APTAI_EPI_SPLIT_OUT = 512     /* out_f32 launches on tile 128 only (exact-index mode): the fp32 result [-> erf GELU with EPI_GELU] leaves as
+    APTAI_EPI_SPLIT_OUT = 512     /* out_f32 launches on tile 128 / 192 / 256 (exact-index mode): the fp32 result [-> erf GELU with EPI_GELU] leaves as
                                    * `split_out_pieces` bf16 pieces in the activation-side layout of aptai_split_f32, [m][N/64][piece][64],
                                    * C = bf16*, ldc (and the C batch strides) in bf16 elements, ldc >= pieces * N: the next split-operand
                                    * GEMM's A operand, written once instead of an fp32 store, a re-read and a split pass */
@@ -144,6 +144,11 @@ int aptai_softmax_split_f32(const float* s, const int32_t* lens, int64_t B, int6
 int aptai_conv0_fwd_f32(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias, const float* gamma,
                         const float* beta, int mode, float eps, float* out, int64_t T_real, int64_t T_alloc, const float* stats,
                         void* stream);
+/* The same layer with its result written as split bf16 pieces [B][T_alloc][512 / 64][piece][64] - the A operand of the exact mode's second
+ * conv layer (round 4: the 1 GB fp32 intermediate at 16 x 10 s is never stored).  Frames in [T_real, T_alloc) are written as zeros. */
+int aptai_conv0_fwd_split(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias, const float* gamma,
+                          const float* beta, int mode, float eps, void* out_split, int pieces, int64_t T_real, int64_t T_alloc,
+                          const float* stats, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ LayerNorm
  * y = (x - mean) * rstd * gamma + beta over the channel axis (cols in {256,512,768,1024}), one wave per row.
