@@ -30,6 +30,7 @@ ARGTYPES = {
     "aptai_layernorm_bwd_workspace_bytes": [_I64, _I64],
     "aptai_layernorm_bwd_finalize_multi": [_P, _I64, _I64, _P],
     "aptai_layernorm_fwd_f32in": [_P, _P, _P, _P, _P, _I64, _I64, _F, _P],
+    "aptai_layernorm_fwd_f32in_split": [_P, _P, _P, _P, _P, _I, _I64, _I64, _F, _P],
     "aptai_attention_fwd": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _U64, _I, _P],
     "aptai_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _U64, _I, _I, _P],
     "aptai_cast_f32_to_bf16": [_P, _P, _I64, _I64, _I64, _P],

@@ -407,6 +407,11 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = (flags & (APTAI_EPI_BIAS | APTAI_EPI_ALPHA)) ? fmaf(v[r], alpha, bias8[r]) : v[r];
             if (OUT_F32) {
+                if (flags & APTAI_EPI_BIAS_ROW) {
+                    const float bm = g.bias[m];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += bm;
+                }
                 if (flags & APTAI_EPI_RESIDUAL_F32) {             // fp32 residual stream (inference-only encoder): += res32[m][n..n+7]
                     const float* R = (const float*)g.residual + (long)m * g.ldr + n;
                     const f32x4 r0 = *(const f32x4*)R, r1 = *(const f32x4*)(R + 4);
@@ -775,7 +780,13 @@ __device__ __forceinline__ void gemm256_epilogue_body(const GemmArgs& g, char* s
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
                     }
-                    if (flags & APTAI_EPI_SPLIT_OUT) { split_out_store(g, flags, v, (long)m, n); continue; }
+                    if (flags & APTAI_EPI_BIAS_ROW) { const float bm = g.bias[m];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += bm; }
+                    if (flags & APTAI_EPI_BIAS_ROW) { const float bm = g.bias[m];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += bm; }
+                if (flags & APTAI_EPI_SPLIT_OUT) { split_out_store(g, flags, v, (long)m, n); continue; }
                     float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
                     *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
                     *(f32x4*)(C + 4) = (f32x4){v[4], v[5], v[6], v[7]};
@@ -1399,6 +1410,9 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm192_kernel(GemmArgs g) {
     #pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
                 }
+                if (flags & APTAI_EPI_BIAS_ROW) { const float bm = g.bias[m];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += bm; }
                 if (flags & APTAI_EPI_SPLIT_OUT) { split_out_store(g, flags, v, (long)m, n); continue; }
                 float* C = (float*)g.C + (long)split * g.slab_stride + (long)m * g.ldc + n;
                 *(f32x4*)C = (f32x4){v[0], v[1], v[2], v[3]};
@@ -1461,6 +1475,9 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     if (d->flags & (APTAI_EPI_DGELU | APTAI_EPI_MUL_AUX)) APTAI_REQUIRE(d->aux != nullptr, "aptai_gemm_bf16: EPI_DGELU / EPI_MUL_AUX without aux");
     if (d->flags & APTAI_EPI_PRE_DGELU) APTAI_REQUIRE(d->out_pre != nullptr && (d->flags & APTAI_EPI_GELU), "aptai_gemm_bf16: EPI_PRE_DGELU needs EPI_GELU and out_pre");
 
+    if (d->flags & APTAI_EPI_BIAS_ROW)
+        APTAI_REQUIRE(d->out_f32 && d->bias != nullptr && !(d->flags & APTAI_EPI_BIAS) && (d->tile == 128 || d->tile == 192 || d->tile == 256) &&
+                      d->split_k <= 1 && !d->accumulate, "aptai_gemm_bf16: EPI_BIAS_ROW needs out_f32, a bias of length M, no EPI_BIAS, tile 128 / 192 / 256");
     if (d->flags & APTAI_EPI_SPLIT_OUT)
         APTAI_REQUIRE(d->out_f32 && (d->tile == 128 || d->tile == 192 || d->tile == 256) && !d->a_kmajor && d->split_k <= 1 && !d->accumulate && (d->split_out_pieces == 3 || d->split_out_pieces == 6) &&
                       d->ldc >= d->split_out_pieces * d->N && d->N % 8 == 0,
@@ -1485,6 +1502,7 @@ static int build_args(const aptai_gemm_desc* d, GemmArgs& g, int& nbatch, int& n
     g.alpha = d->alpha;
     g.colscale_n = d->colscale_n; g.colscale = d->colscale;
     g.split_pieces = d->split_out_pieces;
+    g.split_bcol = (d->flags & APTAI_EPI_SPLIT_OUT) ? d->split_out_bcol : 0;
     g.hash_ld = d->N; g.hash_n0 = 0;
     g.tiles_m = (int)ceil_div(d->M, BM);
     g.tiles_n = (int)ceil_div(d->N, BN);

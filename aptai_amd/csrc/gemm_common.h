@@ -51,6 +51,7 @@ struct GemmArgs {
                                 // wider output (aptai_gemm_bf16 splits some) draws the masks of the whole one
     int colscale_n; float colscale;   // columns [0, colscale_n) of the bf16 output are multiplied by colscale (after alpha / bias)
     int split_pieces;                 // APTAI_EPI_SPLIT_OUT: 3 or 6 bf16 pieces per fp32 result (C is bf16, ldc in bf16 elements)
+    int split_bcol;                   // ... columns >= split_bcol in the weight-side piece order
     // 2-level batching: blockIdx.y = outer * nb_inner + inner; element offsets per level
     int nb_inner;
     long sA[2], sB[2], sC[2], sBias[2], sR[2], sAux[2];
@@ -300,8 +301,14 @@ __device__ __forceinline__ void split_out_store(const GemmArgs& g, const int fla
     auto put = [&](int piece, const float (&q)[8]) {
         *(u32x4*)(dst + piece * 64) = (u32x4){pack2bf(q[0], q[1]), pack2bf(q[2], q[3]), pack2bf(q[4], q[5]), pack2bf(q[6], q[7])};
     };
-    put(0, h); put(1, h); put(2, md);                    // activation side: hi hi lo | hi hi mid mid hi low
-    if (g.split_pieces == 6) { put(3, md); put(4, h); put(5, lw); }
+    put(0, h);
+    if (n < g.split_bcol) {                              // activation side: hi hi lo | hi hi mid mid hi low
+        put(1, h); put(2, md);
+        if (g.split_pieces == 6) { put(3, md); put(4, h); put(5, lw); }
+    } else {                                             // weight side: hi lo hi | hi mid hi mid low hi
+        put(1, md); put(2, h);
+        if (g.split_pieces == 6) { put(3, md); put(4, lw); put(5, h); }
+    }
 }
 
 // 256 x 192 tile kernel (gemm_t4.hip): bf16 output, K-contiguous A, B K-contiguous or K-major; no batching / split-K

@@ -15,7 +15,8 @@ namespace {
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, bf16_t* __restrict__ y,
-                                                         float* __restrict__ y32, long rows, float eps) {
+                                                         float* __restrict__ y32, long rows, float eps,
+                                                         bf16_t* __restrict__ ys = nullptr, int pieces = 0) {
     constexpr int COLS = NCH * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float gm[NCH][4], bt[NCH][4];
@@ -50,6 +51,22 @@ __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict
             for (int r = 0; r < 4; ++r) o[r] = (v[j][r] - mu) * rs * gm[j][r] + bt[j][r];
             if (y) *(u32x2*)(y + row * COLS + (j * 64 + lane) * 4) = (u32x2){pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
             if (y32) *(f32x4*)(y32 + row * COLS + (j * 64 + lane) * 4) = (f32x4){o[0], o[1], o[2], o[3]};
+            if (ys) {               // exact-index mode: the normalised row also leaves as the next product's split A operand (activation side)
+                float h[4], md[4], lw[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) split3(o[r], h[r], md[r], lw[r]);
+                const int c = (j * 64 + lane) * 4;
+                bf16_t* dst = ys + row * ((long)COLS * pieces) + (long)(c >> 6) * (64 * pieces) + (c & 63);
+                const u32x2 ph = {pack2bf(h[0], h[1]), pack2bf(h[2], h[3])}, pm = {pack2bf(md[0], md[1]), pack2bf(md[2], md[3])};
+                *(u32x2*)dst = ph;
+                *(u32x2*)(dst + 64) = ph;
+                *(u32x2*)(dst + 128) = pm;
+                if (pieces == 6) {
+                    *(u32x2*)(dst + 192) = pm;
+                    *(u32x2*)(dst + 256) = ph;
+                    *(u32x2*)(dst + 320) = (u32x2){pack2bf(lw[0], lw[1]), pack2bf(lw[2], lw[3])};
+                }
+            }
         }
     }
 }
@@ -348,7 +365,7 @@ extern "C" int aptai_layernorm_fwd_f32in(const float* x, const float* gamma, con
     APTAI_REQUIRE(cols % 256 == 0 && cols >= 256 && cols <= 1024, "aptai_layernorm_fwd_f32in: cols=%ld (need 256..1024, %%256)", (long)cols);
     long blocks = ceil_div(rows, 4);
     if (blocks > 2048) blocks = 2048;
-#define LN_FWD32(NCH) APTAI_LAUNCH(ln_fwd_f32_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, (long)rows, eps)
+#define LN_FWD32(NCH) APTAI_LAUNCH(ln_fwd_f32_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, (long)rows, eps, (bf16_t*)nullptr, 0)
     switch (cols / 256) {
         case 1: LN_FWD32(1); break;
         case 2: LN_FWD32(2); break;
@@ -357,6 +374,26 @@ extern "C" int aptai_layernorm_fwd_f32in(const float* x, const float* gamma, con
     }
 #undef LN_FWD32
     APTAI_CHECK_LAUNCH("ln_fwd_f32_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_layernorm_fwd_f32in_split(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_split, int pieces,
+                                               int64_t rows, int64_t cols, float eps, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    APTAI_REQUIRE(x && gamma && beta && y_split, "aptai_layernorm_fwd_f32in_split: null pointer");
+    APTAI_REQUIRE(rows > 0 && (pieces == 3 || pieces == 6), "aptai_layernorm_fwd_f32in_split: rows=%ld pieces=%d", (long)rows, pieces);
+    APTAI_REQUIRE(cols % 256 == 0 && cols >= 256 && cols <= 1024, "aptai_layernorm_fwd_f32in_split: cols=%ld (need 256..1024, %%256)", (long)cols);
+    long blocks = ceil_div(rows, 4);
+    if (blocks > 2048) blocks = 2048;
+#define LN_FWD32S(NCH) APTAI_LAUNCH(ln_fwd_f32_kernel<NCH>, dim3((unsigned)blocks), dim3(256), 0, stream, x, gamma, beta, (bf16_t*)nullptr, y_f32, (long)rows, eps, (bf16_t*)y_split, pieces)
+    switch (cols / 256) {
+        case 1: LN_FWD32S(1); break;
+        case 2: LN_FWD32S(2); break;
+        case 3: LN_FWD32S(3); break;
+        default: LN_FWD32S(4); break;
+    }
+#undef LN_FWD32S
+    APTAI_CHECK_LAUNCH("ln_fwd_f32_kernel (split)");
     return APTAI_OK;
 }
 

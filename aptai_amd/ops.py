@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_DGELU, EPI_ALPHA, EPI_PRE_DGELU, EPI_MUL_AUX, EPI_RESIDUAL_F32, EPI_SPLIT_OUT = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_DGELU, EPI_ALPHA, EPI_PRE_DGELU, EPI_MUL_AUX, EPI_RESIDUAL_F32, EPI_SPLIT_OUT, EPI_BIAS_ROW = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 
 c_void_p, c_i64, c_int, c_float, c_u64 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float,
                                           ctypes.c_uint64)
@@ -28,7 +28,7 @@ class GemmDesc(ctypes.Structure):
                 ("batch_stride_a", c_i64 * 2), ("batch_stride_b", c_i64 * 2), ("batch_stride_c", c_i64 * 2),
                 ("batch_stride_bias", c_i64 * 2), ("batch_stride_res", c_i64 * 2), ("batch_stride_aux", c_i64 * 2),
                 ("tile", c_int), ("colscale_n", c_int), ("colscale", c_float),
-                ("sk_workspace", c_void_p), ("sk_workspace_bytes", c_i64), ("split_out_pieces", c_int)]
+                ("sk_workspace", c_void_p), ("sk_workspace_bytes", c_i64), ("split_out_pieces", c_int), ("split_out_bcol", c_int)]
 
 
 TILE_STREAMK = 257
@@ -102,7 +102,7 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
                a_kmajor=False, b_kmajor=False, out_f32=False, bias=None, gelu=False, residual=None, out_pre=None,
                dgelu_aux=None, alpha: Optional[float] = None, dropout_p: float = 0.0, seed: int = 0, split_k: int = 1,
                accumulate: bool = False, workspace: Optional[torch.Tensor] = None, batch=None, ldr=None, tile: int = 0,
-               ldaux=None, pre_dgelu: bool = False, mul_aux=None, colscale=None, residual_f32=None, split_out=None):
+               ldaux=None, pre_dgelu: bool = False, mul_aux=None, colscale=None, residual_f32=None, split_out=None, split_bcol=None, bias_row=None):
     """Fills one aptai_gemm_desc in place; returns (out, workspace) - the caller keeps them alive across the launch."""
     _dev(a, b, out, bias, residual, out_pre, dgelu_aux, mul_aux)
     if out is None:
@@ -144,11 +144,16 @@ def _gemm_desc(d: "GemmDesc", a: torch.Tensor, b: torch.Tensor, M: int, N: int, 
     if dropout_p > 0:
         flags |= EPI_DROPOUT
         d.dropout_p, d.seed = dropout_p, seed
+    if bias_row is not None:       # fp32-output launches: bias indexed by the output row (a product evaluated transposed)
+        _dev(bias_row)
+        flags |= EPI_BIAS_ROW
+        d.bias = bias_row.data_ptr()
     if split_out:
         if out.dtype != torch.bfloat16 or not out_f32:
             raise ValueError("split_out writes bf16 pieces from an out_f32 launch")
         flags |= EPI_SPLIT_OUT
         d.split_out_pieces = int(split_out)
+        d.split_out_bcol = int(split_bcol) if split_bcol is not None else int(N)
     d.flags = flags
     d.split_k, d.accumulate = split_k, int(accumulate)
     d.tile = tile if tile else _AUTO_TILE
@@ -360,7 +365,7 @@ def conv0_fwd_f32(audio, weight, bias, gamma, beta, mode, out32, T_real, T_alloc
 
 
 def gemm_split(a_s: torch.Tensor, w_s: torch.Tensor, M: int, N: int, K: int, pieces: int, *, lda=None, bias=None, residual_f32=None,
-               out=None, ldc=None, split_out: bool = False, gelu: bool = False) -> torch.Tensor:
+               out=None, ldc=None, split_out: bool = False, gelu: bool = False, split_bcol=None) -> torch.Tensor:
     """fp32 C[M][N] = A . W^T (+ bias) (+ fp32 residual) from split operands (split_f32): one NT launch of K' = pieces * K.
     split_out: the result (after the erf GELU when `gelu`) is returned as split bf16 pieces [M][pieces N] instead - the next product's A."""
     # fp32-output launches name their tile (include/aptai_hip.h); whole rounds of 256 x 256 tiles where the output has them (the conv
@@ -371,7 +376,7 @@ def gemm_split(a_s: torch.Tensor, w_s: torch.Tensor, M: int, N: int, K: int, pie
     if tile == 128 and M % 128 == 0 and N % 192 == 0 and 192 < (M // 128) * (N // 192) <= 256:
         tile = 192
     return gemm(a_s, w_s, M, N, K * pieces, lda=(lda * pieces if lda is not None else None), out_f32=True, bias=bias, gelu=(gelu and split_out),
-                residual_f32=residual_f32, out=out, ldc=ldc, tile=tile, split_out=(pieces if split_out else None))
+                residual_f32=residual_f32, out=out, ldc=ldc, tile=tile, split_out=(pieces if split_out else None), split_bcol=split_bcol)
 
 
 # ----------------------------------------------------------------------------- LayerNorm
@@ -454,6 +459,16 @@ def layernorm_fwd_f32in(x32, gamma, beta, eps, *, want_bf16=True, want_f32=True)
     y32 = torch.empty((rows, cols), device=x32.device, dtype=torch.float32) if want_f32 else None
     _lib.call("aptai_layernorm_fwd_f32in", x32.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(y), _ptr(y32), rows, cols, eps, _stream())
     return y, y32
+
+
+def layernorm_fwd_f32in_split(x32, gamma, beta, eps, pieces, *, want_f32=True):
+    """nn.LayerNorm on an fp32 activation -> (fp32 copy | None, split bf16 pieces [rows][pieces cols]) (aptai_layernorm_fwd_f32in_split)."""
+    _dev(x32, gamma, beta)
+    rows, cols = x32.shape
+    y32 = torch.empty((rows, cols), device=x32.device, dtype=torch.float32) if want_f32 else None
+    ys = torch.empty((rows, cols * pieces), device=x32.device, dtype=torch.bfloat16)
+    _lib.call("aptai_layernorm_fwd_f32in_split", x32.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(y32), ys.data_ptr(), pieces, rows, cols, eps, _stream())
+    return y32, ys
 
 
 def attention_qscale(H: int, heads: int) -> float:

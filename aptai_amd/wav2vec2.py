@@ -907,39 +907,42 @@ class Wav2Vec2Model(nn.Module):
             for i in range(len(self.encoder.layers)):
                 p = [t.detach() for t in self._layer_params(i)]
                 w.layers.append(SimpleNamespace(
-                    wqkv=ops.split_f32(torch.cat(p[0:3]).contiguous(), P, weight_side=True), bqkv=torch.cat(p[3:6]).contiguous(),
+                    wqk=ops.split_f32(torch.cat(p[0:2]).contiguous(), P, weight_side=True), bqk=torch.cat(p[3:5]).contiguous(),
+                    wv=ops.split_f32(p[2].contiguous(), P, weight_side=True), bv=p[5].contiguous(),
                     wo=ops.split_f32(p[6].contiguous(), P, weight_side=True), bo=p[7],
                     w1=ops.split_f32(p[8].contiguous(), P, weight_side=True), b1=p[9],
                     w2=ops.split_f32(p[10].contiguous(), P, weight_side=True), b2=p[11]))
             return w
         return self._cached(("exact", P), params, build)
 
-    def _exact_attention(self, qkv32, lens_i32, g, P=3):
-        """softmax(Q K^T / sqrt(d) + key mask) V per head (HF:438-548) at fp32-class accuracy.  Round 4: both products as SPLIT-OPERAND
-        bf16 GEMMs, batched over (utterance, head) - two launches per layer on the 2.5 PF pipe instead of 24 on the fp32 matrix
-        instruction (157 TF; the exact-mode step spent 10 of its 27 ms there).  Per head the 64 feature columns are exactly one K-tile
-        of aptai_split_f32's interleaved layout, so head h of the split Q / K is the column block [h * 64 P, (h + 1) * 64 P): the batch
-        strides of aptai_gemm_bf16 walk heads and utterances, nothing is re-packed.  Scores [B][heads][Tp][Tp] stay fp32 (softmax
-        in fp32, masked keys exactly 0); the probabilities leave the softmax pass already split like every other activation, V is transposed once so that its
-        key axis is the contiguous K of an NT product."""
+    def _exact_attention(self, a_s, w, lens_i32, g, P=3):
+        """q|k|v projection + softmax(Q K^T / sqrt(d) + key mask) V per head (HF:438-548) at fp32-class accuracy, from the layer input's
+        split pieces `a_s` [M][P H].  Round 4: every product is a SPLIT-OPERAND bf16 GEMM and no fp32 tensor but the scores is stored.
+          * q|k projection: one launch, its result leaves already split (APTAI_EPI_SPLIT_OUT): Q in the activation-side piece order, K
+            (columns >= H, `split_out_bcol`) in the weight-side order - the two operands of Q K^T.  Per head the 64 feature columns are
+            exactly one K-tile of the split layout, so head h is the column block [64 P h, 64 P (h + 1)) and the batch strides of
+            aptai_gemm_bf16 walk heads and utterances: nothing is re-packed;
+          * V is projected TRANSPOSED, V^T [H][M] = W_v . X^T (the weight as the row operand, its Linear bias along the rows:
+            APTAI_EPI_BIAS_ROW), and leaves split along the key axis in the weight-side order: the B operand of P . V as it is;
+          * scores [B][heads][Tp][Tp] fp32 -> aptai_softmax_split_f32 -> P . V, whose result leaves as the out-projection's split A.
+        (Round 3: 24 launches per layer on the fp32 matrix instruction, 10 of the mode's 27 ms.)"""
         cfg = self.config
         H, heads, B, Tp, M = cfg.hidden_size, cfg.num_attention_heads, g.B, g.Tp, g.M
         d = H // heads
         if d != 64:
             raise NotImplementedError("the exact attention is built for head_dim 64 (one K-tile of the split layout per head)")
-        dev = qkv32.device
-        qs = ops.split_f32(qkv32, P, cols=H)                                   # [M][P H]  (hi, hi, lo per 64 columns)
-        ks = ops.split_f32(qkv32[:, H:], P, cols=H, weight_side=True)           # [M][P H]  (hi, lo, hi)
+        dev = a_s.device
+        qks = ops.gemm_split(a_s, w.wqk, M, 2 * H, H, P, bias=w.bqk, split_out=True, split_bcol=H)          # [M][P 2H]: Q | K
+        vts = torch.empty((H, P * M), device=dev, dtype=torch.bfloat16)                                      # V^T, split along the keys
+        ops.gemm(w.wv, a_s, H, M, P * H, out=vts, ldc=P * M, out_f32=True, tile=128, bias_row=w.bv, split_out=P, split_bcol=0)
         s32 = torch.empty((B, heads, Tp, Tp), device=dev, dtype=torch.float32)
-        ops.gemm(qs, ks, Tp, Tp, P * d, lda=P * H, ldb=P * H, out=s32, ldc=Tp, out_f32=True, alpha=d ** -0.5, tile=128,
-                 batch=dict(outer=B, inner=heads, a=(Tp * P * H, P * d), b=(Tp * P * H, P * d), c=(heads * Tp * Tp, Tp * Tp)))
+        ops.gemm(qks, qks[:, P * H:], Tp, Tp, P * d, lda=2 * P * H, ldb=2 * P * H, out=s32, ldc=Tp, out_f32=True, alpha=d ** -0.5, tile=128,
+                 batch=dict(outer=B, inner=heads, a=(Tp * 2 * P * H, P * d), b=(Tp * 2 * P * H, P * d), c=(heads * Tp * Tp, Tp * Tp)))
         ps = ops.softmax_split_f32(s32, lens_i32, B, heads, Tp, P)              # [B heads Tp][P Tp]: softmax + split in one pass
-        vt = qkv32[:, 2 * H:].reshape(B, Tp, heads, d).permute(0, 2, 3, 1).contiguous()            # [B][heads][d][Tp] fp32
-        vts = ops.split_f32(vt.view(B * heads * d, Tp), P, weight_side=True)    # [B heads d][P Tp]
         # the context leaves as the out-projection's split A operand (head h = K-tile h of the split layout: column block h * 64 P)
         ctx_s = torch.empty((M, P * H), device=dev, dtype=torch.bfloat16)
-        ops.gemm(ps, vts, Tp, d, P * Tp, lda=P * Tp, ldb=P * Tp, out=ctx_s, ldc=P * H, out_f32=True, tile=128, split_out=P,
-                 batch=dict(outer=B, inner=heads, a=(heads * Tp * P * Tp, Tp * P * Tp), b=(heads * d * P * Tp, d * P * Tp), c=(Tp * P * H, P * d)))
+        ops.gemm(ps, vts, Tp, d, P * Tp, lda=P * Tp, ldb=P * M, out=ctx_s, ldc=P * H, out_f32=True, tile=128, split_out=P,
+                 batch=dict(outer=B, inner=heads, a=(heads * Tp * P * Tp, Tp * P * Tp), b=(Tp * P, d * P * M), c=(Tp * P * H, P * d)))
         return ctx_s
 
     def _forward_exact(self, audio, g, lens_i32, P, output_hidden_states):
@@ -1023,34 +1026,33 @@ class Wav2Vec2Model(nn.Module):
         ops.gemm(xs, W.posconv, g.Tp, Cg, KP, lda=P * 64, ldb=KP, out=conv, ldc=H, out_f32=True, bias=pc.bias, tile=128,
                  batch=dict(outer=G, inner=g.B, a=(g.B * rows_p * P * 64, rows_p * P * 64), b=(Cg * KP, 0), c=(Cg, g.Tp * H), bias=(Cg, 0)))
         h = ops.bias_act_res_f32(conv, gelu=True, res=h0)
+        h_s = None                                           # split pieces of h where a LayerNorm has just produced them
         if not cfg.do_stable_layer_norm:
-            _, h = ops.layernorm_fwd_f32in(h, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias, eps, want_bf16=False)
-        # ---- transformer layers (HF:575-654)
+            h, h_s = ops.layernorm_fwd_f32in_split(h, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias, eps, P)
+        # ---- transformer layers (HF:575-654).  Every LayerNorm whose result feeds a product also writes it split (round 4).
         hidden = []
         for i, layer in enumerate(self.encoder.layers):
             hidden.append(h)
             w = W.layers[i]
             ln1, ln2 = layer.layer_norm, layer.final_layer_norm
             if cfg.do_stable_layer_norm:
-                _, a_in = ops.layernorm_fwd_f32in(h, ln1.weight, ln1.bias, eps, want_bf16=False)
+                _, a_s = ops.layernorm_fwd_f32in_split(h, ln1.weight, ln1.bias, eps, P, want_f32=False)
             else:
-                a_in = h
-            qkv = ops.gemm_split(ops.split_f32(a_in, P), w.wqkv, M, 3 * H, H, P, bias=w.bqkv)
-            ctx = self._exact_attention(qkv, lens_i32, g, P)
+                a_s = h_s if h_s is not None else ops.split_f32(h, P)
+            ctx = self._exact_attention(a_s, w, lens_i32, g, P)
             s1 = ops.gemm_split(ctx, w.wo, M, H, H, P, bias=w.bo, residual_f32=h)          # ctx: already split
             if cfg.do_stable_layer_norm:
-                _, f_in = ops.layernorm_fwd_f32in(s1, ln2.weight, ln2.bias, eps, want_bf16=False)
+                _, f_s = ops.layernorm_fwd_f32in_split(s1, ln2.weight, ln2.bias, eps, P, want_f32=False)
                 res2 = s1
             else:
-                _, f_in = ops.layernorm_fwd_f32in(s1, ln1.weight, ln1.bias, eps, want_bf16=False)
-                res2 = f_in
+                res2, f_s = ops.layernorm_fwd_f32in_split(s1, ln1.weight, ln1.bias, eps, P)
             # FFN1's result leaves its GEMM already GELU'd and split (EPI_SPLIT_OUT): 100 MB of fp32 and a split pass less per layer
-            us = ops.gemm_split(ops.split_f32(f_in, P), w.w1, M, I, H, P, bias=w.b1, split_out=True, gelu=True)
+            us = ops.gemm_split(f_s, w.w1, M, I, H, P, bias=w.b1, split_out=True, gelu=True)
             s2 = ops.gemm_split(us, w.w2, M, H, I, P, bias=w.b2, residual_f32=res2)
             if cfg.do_stable_layer_norm:
-                h = s2
+                h, h_s = s2, None
             else:
-                _, h = ops.layernorm_fwd_f32in(s2, ln2.weight, ln2.bias, eps, want_bf16=False)
+                h, h_s = ops.layernorm_fwd_f32in_split(s2, ln2.weight, ln2.bias, eps, P)
         if cfg.do_stable_layer_norm:
             _, h = ops.layernorm_fwd_f32in(h, self.encoder.layer_norm.weight, self.encoder.layer_norm.bias, eps, want_bf16=False)
         hidden.append(h)

@@ -64,6 +64,8 @@ enum {
     APTAI_EPI_MUL_AUX = 128,  /* *= aux[m*ldaux+n] (bf16): the backward partner of EPI_PRE_DGELU */
     APTAI_EPI_RESIDUAL_F32 = 256, /* fp32 output only (tile 64 / 128 / 192): += residual[m*ldr+n] read as FP32 - the residual stream of the
                                    * inference-only encoder kept in fp32 (HF:594-601: hidden_states = attn_residual + hidden_states) */
+    APTAI_EPI_BIAS_ROW = 1024,    /* out_f32 launches only: bias is indexed by the output ROW (bias[m], length M) - a product evaluated transposed,
+                                   * C^T = W . X^T, carries its Linear bias along the rows (the exact mode's V^T projection) */
     APTAI_EPI_SPLIT_OUT = 512     /* out_f32 launches on tile 128 / 192 / 256 (exact-index mode): the fp32 result [-> erf GELU with EPI_GELU] leaves as
                                    * `split_out_pieces` bf16 pieces in the activation-side layout of aptai_split_f32, [m][N/64][piece][64],
                                    * C = bf16*, ldc (and the C batch strides) in bf16 elements, ldc >= pieces * N: the next split-operand
@@ -101,6 +103,9 @@ typedef struct {
                                        auto rule may pick the stream-K form; without it tile 257 is refused and auto never picks it */
     int64_t sk_workspace_bytes;
     int split_out_pieces;           /* with APTAI_EPI_SPLIT_OUT: 3 or 6 */
+    int split_out_bcol;             /* with APTAI_EPI_SPLIT_OUT: output columns n >= split_out_bcol are written in the WEIGHT-side piece order
+                                       (hi lo hi | hi mid hi mid low hi), columns below it in the activation-side order; N (or more) = all
+                                       activation-side.  A fused q|k projection hands Q (A operand of Q K^T) and K (its B operand) over at once */
 } aptai_gemm_desc;
 
 int aptai_gemm_bf16(const aptai_gemm_desc* desc, void* stream);
@@ -162,6 +167,10 @@ int aptai_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
  * normalised row (bf16 for the next GEMM operand, fp32 for the next residual add).  cols in {256, 512, 768, 1024}. */
 int aptai_layernorm_fwd_f32in(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, int64_t rows,
                               int64_t cols, float eps, void* stream);
+/* The same LayerNorm with its result ALSO written as split bf16 pieces [rows][cols / 64][piece][64] (activation-side order): the A operand of
+ * the exact mode's next split-operand product, without a split pass of its own.  y_f32 may be null. */
+int aptai_layernorm_fwd_f32in_split(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_split, int pieces,
+                                    int64_t rows, int64_t cols, float eps, void* stream);
 int aptai_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         const void* dres, void* dx, void* dx_drop, float dropout_p, uint64_t seed, float* dgamma,
                         float* dbeta, void* workspace, int64_t rows, int64_t cols, const float* beta_if_gelu_after,
