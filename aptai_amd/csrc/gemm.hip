@@ -458,6 +458,21 @@ __device__ __forceinline__ void gemm_tile_body(GemmArgs g, const int bid, const 
 
 template <bool A_KM, bool B_KM, bool OUT_F32>
 __global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel(GemmArgs g) {
+#ifdef APTAI_EXP_STAGGER
+    if (g.exp_sleep > 0) {
+        bool late = true;
+        if (g.exp_cu_count != nullptr) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            __shared__ unsigned arrival;
+            if (threadIdx.x == 0) arrival = atomicAdd(g.exp_cu_count + ((xcc & 7u) * 256u + ((hwid >> 8) & 0xffu)), 1u);
+            __syncthreads();
+            late = (arrival & 1u) != 0;
+        }
+        if (late) for (int i = 0; i < g.exp_sleep; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     gemm_tile_body<A_KM, B_KM, OUT_F32>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), gridDim.y > 1 ? (int)blockIdx.y : -1,
                                         blockIdx.z);
 }
@@ -522,6 +537,21 @@ int launch_gemm(const GemmArgs& g, int nbatch, int nsplit, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid(g.tiles_m * g.tiles_n, nbatch, nsplit);
+#ifdef APTAI_EXP_STAGGER
+    {   // development: per-call sleep and LDS request (occupancy) from the environment (tools/stagger_probe.py)
+        GemmArgs ge = g;
+        const char* e = getenv("APTAI_EXP_SLEEP");
+        ge.exp_sleep = e ? atoi(e) : 0;
+        const char* c = getenv("APTAI_EXP_CU_COUNT");          // device pointer (decimal) of 2048 zeroed words
+        ge.exp_cu_count = c ? (unsigned*)(uintptr_t)strtoull(c, nullptr, 10) : nullptr;
+        const char* m = getenv("APTAI_EXP_SMEM");
+        const int sm = m ? atoi(m) : smem;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, sm > smem ? sm : smem);
+        APTAI_LAUNCH(kern, grid, dim3(NTHREADS), sm > smem ? sm : smem, stream, ge);
+        APTAI_CHECK_LAUNCH("gemm_kernel");
+        return APTAI_OK;
+    }
+#endif
     APTAI_LAUNCH(kern, grid, dim3(NTHREADS), smem, stream, g);
     APTAI_CHECK_LAUNCH("gemm_kernel");
     return APTAI_OK;

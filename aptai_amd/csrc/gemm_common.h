@@ -52,6 +52,10 @@ struct GemmArgs {
     int colscale_n; float colscale;   // columns [0, colscale_n) of the bf16 output are multiplied by colscale (after alpha / bias)
     int split_pieces;                 // APTAI_EPI_SPLIT_OUT: 3 or 6 bf16 pieces per fp32 result (C is bf16, ldc in bf16 elements)
     int split_bcol;                   // ... columns >= split_bcol in the weight-side piece order
+#ifdef APTAI_EXP_STAGGER
+    int exp_sleep;                    // development (tools/ab builds): s_sleep(127) iterations at the start of every SECOND block to arrive on a CU
+    unsigned* exp_cu_count;           // ... per-CU arrival counters (2048 words, zeroed by the caller before the launch), or null = every block sleeps
+#endif
     // 2-level batching: blockIdx.y = outer * nb_inner + inner; element offsets per level
     int nb_inner;
     long sA[2], sB[2], sC[2], sBias[2], sR[2], sAux[2];
