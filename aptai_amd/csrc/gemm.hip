@@ -468,9 +468,9 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_kernel(GemmArgs g) {
             __shared__ unsigned arrival;
             if (threadIdx.x == 0) arrival = atomicAdd(g.exp_cu_count + ((xcc & 7u) * 256u + ((hwid >> 8) & 0xffu)), 1u);
             __syncthreads();
-            late = (arrival & 1u) != 0;
+            late = arrival == 1u;        // the CU's second block of the FIRST round only: later blocks inherit the offset
         }
-        if (late) for (int i = 0; i < g.exp_sleep; ++i) __builtin_amdgcn_s_sleep(127);
+        if (late) for (int i = 0; i < g.exp_sleep; ++i) __builtin_amdgcn_s_sleep(31);   // ~1 us each
     }
 #endif
     gemm_tile_body<A_KM, B_KM, OUT_F32>(g, xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n), gridDim.y > 1 ? (int)blockIdx.y : -1,

@@ -391,10 +391,34 @@ class GraphedAPTAIStep:
                 self.g_ln = mk()
                 with torch.cuda.graph(self.g_ln, pool=pool, stream=self._cap_stream, capture_error_mode=_CAPTURE_MODE):
                     ops.ln_finalize_multi(self._ln_table, n_jobs, max_cols)
+        # optimiser under the backward pass (step()): the parameters of layer i whose gradients are final when its backward segment ends
+        self.adam_overlap = (self.group_reducer is None and not self.overlap_wgrad and hasattr(self.opt, "launch_early")
+                             and os.environ.get("APTAI_ADAM_OVERLAP", "0") != "0")
+        self._o_stream = torch.cuda.Stream(device=self.dev) if self.adam_overlap else None
+        self._early_params = [[p for k, (p, _) in enumerate(self.layer_grads[i]) if p.requires_grad and (k >= 4 or self.g_ln is None)]
+                              for i in range(L)]
         # the graphs hold raw addresses of the compute copies in the model's cache: keep them alive for this runner's lifetime (a
         # second runner of the same model - another shape bucket - clears and rebuilds the cache for its own capture)
         self._keep_cache = dict(w._cache)
         torch.cuda.synchronize()
+
+    def _assign_grads(self, keep) -> None:
+        """Every trainable parameter's `.grad` = its static gradient buffer (None for a layer LayerDrop skipped this step)."""
+        for p, gt in self.grads.items():
+            if p.requires_grad:
+                p.grad = gt
+        for i in range(self.cfg.num_hidden_layers):
+            for p, gt in self.layer_grads[i]:
+                if p.requires_grad:
+                    p.grad = gt if keep[i] else None
+        if not getattr(self, "_checked", False):
+            names = {id(p): n for n, p in self.model.named_parameters()}
+            for p in self.model.parameters():
+                if p.grad is not None and (p.grad.dtype != p.dtype or p.grad.shape != p.shape or not p.grad.is_contiguous()
+                                           or p.grad.device != p.device):
+                    raise RuntimeError(f"static gradient of {names[id(p)]} has dtype {p.grad.dtype} shape {tuple(p.grad.shape)} "
+                                       f"contiguous={p.grad.is_contiguous()} (parameter: {p.dtype} {tuple(p.shape)})")
+            self._checked = True
 
     # ------------------------------------------------------------------ one optimiser step
     def step(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
@@ -405,6 +429,17 @@ class GraphedAPTAIStep:
         self.w._train_marker = getattr(self.w, "_train_marker", 0) + 1     # eval-mode weight copies built before this step are stale
         if self.loss_norm is not None:
             self.loss_norm.begin(self.tv_tgt, self.phn_tgt)      # travels under the encoder forward
+        # Optimiser under the backward pass (APTAI_ADAM_OVERLAP=1; experiment, OFF by default; single GPU, aptai_amd.optim.Adam): a
+        # layer's six weight / bias pairs are updated on a side stream as soon as its backward segment has finished - an HBM-bound
+        # launch beside the next layers' matrix-bound ones.  Adam is element-wise per parameter, so WHEN a parameter is updated
+        # changes no bit (tests/test_gpu_graphed.py).  Measured, interleaved on one box: 8.97 / 8.97 / 8.97 ms without, 9.15 / 9.15 /
+        # 9.21 ms with - the 0.34 ms of Adam cost 0.52 ms beside the GEMMs (2.8 GB streamed through the L2s their operand panels
+        # live in).  (The layer's LayerNorm gradients are final only after the deferred finalize launch: they stay with finish().)
+        overlap_opt = self.adam_overlap
+        if overlap_opt:
+            self._assign_grads(keep)
+            early = [self._early_params[i] if keep[i] else [] for i in range(L)]
+            self.opt.prepare(early=[p for lst in early for p in lst])
         self.g_prep.replay()
         self.g_front.replay()
         for i in range(L):
@@ -418,7 +453,7 @@ class GraphedAPTAIStep:
         self.g_tail.replay()
         if red is not None:
             red.launch("heads", [gt for p, gt in self.grads.items() if p.requires_grad and any(p is q for q in self.hparams)])
-        cur = torch.cuda.current_stream(self.dev) if self.overlap_wgrad else None
+        cur = torch.cuda.current_stream(self.dev) if (self.overlap_wgrad or overlap_opt) else None
         for i in range(L - 1, -1, -1):
             if keep[i]:
                 self.g_bwd[i].replay()
@@ -426,6 +461,9 @@ class GraphedAPTAIStep:
                     self._w_stream.wait_stream(cur)
                     with torch.cuda.stream(self._w_stream):
                         self.g_bww[i].replay()
+                if overlap_opt and early[i]:
+                    self._o_stream.wait_stream(cur)
+                    self.opt.launch_early(early[i], self._o_stream)
                 if red is not None:            # layer i's gradients travel while layer i-1's backward runs
                     red.launch(("layer", i), self._layer_grad_tensors(i))
             else:
@@ -438,22 +476,13 @@ class GraphedAPTAIStep:
         if red is not None:
             red.launch("front", [gt for p, gt in self.grads.items() if p.requires_grad and not any(p is q for q in self.hparams)])
             red.finish()
-        for p, gt in self.grads.items():
-            if p.requires_grad:
-                p.grad = gt
-        for i in range(L):
-            for p, gt in self.layer_grads[i]:
-                if p.requires_grad:
-                    p.grad = gt if keep[i] else None
-        if not getattr(self, "_checked", False):
-            names = {id(p): n for n, p in self.model.named_parameters()}
-            for p in self.model.parameters():
-                if p.grad is not None and (p.grad.dtype != p.dtype or p.grad.shape != p.shape or not p.grad.is_contiguous()
-                                           or p.grad.device != p.device):
-                    raise RuntimeError(f"static gradient of {names[id(p)]} has dtype {p.grad.dtype} shape {tuple(p.grad.shape)} "
-                                       f"contiguous={p.grad.is_contiguous()} (parameter: {p.dtype} {tuple(p.shape)})")
-            self._checked = True
-        self.opt.step()
+        if not overlap_opt:
+            self._assign_grads(keep)
+        if overlap_opt:
+            cur.wait_stream(self._o_stream)    # (the next step's prep segment reads what these launches wrote)
+            self.opt.finish()
+        else:
+            self.opt.step()
         if self.kind == "pr":
             loss, logits, log_probs, hd = self.outs
             g, V = self.g, self.hparams[0].shape[0]
@@ -706,6 +735,24 @@ class GraphedForceStep:
         ev = torch.cuda.Event()
         ev.record()
         self._salt_events[slot] = ev
+
+    def _assign_grads(self, keep) -> None:
+        """Every trainable parameter's `.grad` = its static gradient buffer (None for a layer LayerDrop skipped this step)."""
+        for p, gt in self.grads.items():
+            if p.requires_grad:
+                p.grad = gt
+        for i in range(self.cfg.num_hidden_layers):
+            for p, gt in self.layer_grads[i]:
+                if p.requires_grad:
+                    p.grad = gt if keep[i] else None
+        if not getattr(self, "_checked", False):
+            names = {id(p): n for n, p in self.model.named_parameters()}
+            for p in self.model.parameters():
+                if p.grad is not None and (p.grad.dtype != p.dtype or p.grad.shape != p.shape or not p.grad.is_contiguous()
+                                           or p.grad.device != p.device):
+                    raise RuntimeError(f"static gradient of {names[id(p)]} has dtype {p.grad.dtype} shape {tuple(p.grad.shape)} "
+                                       f"contiguous={p.grad.is_contiguous()} (parameter: {p.dtype} {tuple(p.shape)})")
+            self._checked = True
 
     # ------------------------------------------------------------------ one optimiser step
     def step(self, batch: Optional[Dict[str, torch.Tensor]] = None, next_batch: Optional[Dict[str, torch.Tensor]] = None):

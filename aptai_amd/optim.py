@@ -42,7 +42,7 @@ class Adam(torch.optim.Optimizer):
     # ------------------------------------------------------------------ step
     def _group_tables(self, gi: int, group):
         """Static job table of a parameter group (all its parameters, whether or not they get a gradient this step) and a
-        small ring of pinned host buffers for the per-step column {grad pointer, step count}."""
+        small ring of pinned host buffers for the per-step columns {grad pointer, step count} (two planes: prepare())."""
         key = tuple(p.data_ptr() for p in group["params"])
         cached = self._tables.get(gi)
         if cached is not None and cached["key"] == key:
@@ -63,8 +63,8 @@ class Adam(torch.optim.Optimizer):
                          p.numel(), kind])
         dev = params[0].device
         cached = dict(key=key, table=torch.tensor(rows, dtype=torch.int64).to(dev), max_n=max(r[4] for r in rows),
-                      dyn_dev=torch.zeros((len(params), 2), dtype=torch.int64, device=dev),
-                      ring=[torch.zeros((len(params), 2), dtype=torch.int64).pin_memory() for _ in range(4)],
+                      numels=[r[4] for r in rows], dyn_dev=torch.zeros((2, len(params), 2), dtype=torch.int64, device=dev),
+                      ring=[torch.zeros((2, len(params), 2), dtype=torch.int64).pin_memory() for _ in range(4)],
                       events=[None] * 4, turn=0, states=[self.state[p] for p in params], params=params, others=others)
         self._tables[gi] = cached
         return cached
@@ -75,7 +75,20 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.prepare()
+        self.finish()
+        return loss
+
+    # ------------------------------------------------------------------ the step in pieces (aptai_amd.graphed: optimiser under the backward pass)
+    @torch.no_grad()
+    def prepare(self, early=()) -> None:
+        """Host half of step(): step counts and the per-step {gradient pointer, step} column of every group, copied to the device
+        on the current stream.  `early` names parameters whose update will be launched by launch_early() (once their gradient is
+        final, on any stream ordered behind this call) before finish() updates the rest.  Every parameter's `.grad` must already
+        be the tensor its gradient WILL be in (static gradient buffers): the kernel reads it only when it is launched."""
         stream = torch.cuda.current_stream()
+        early_ids = {id(p) for p in early}
+        self._pending = []
         for gi, group in enumerate(self.param_groups):
             if not any(p.is_cuda for p in group["params"]):
                 if any(p.grad is not None for p in group["params"]):
@@ -89,31 +102,55 @@ class Adam(torch.optim.Optimizer):
             t["turn"] = (slot + 1) % len(t["ring"])
             if t["events"][slot] is not None:
                 t["events"][slot].synchronize()        # the copy that last used this pinned buffer has been consumed
-            host = t["ring"][slot].numpy()
-            any_grad = False
+            host = t["ring"][slot].numpy()             # [2][n][2]: plane 0 = rows finish() updates, plane 1 = rows launch_early() updates
+            host[:, :, 0] = 0
+            any_late = any_early = False
             for j, (p, st) in enumerate(zip(params, t["states"])):
                 g = p.grad
                 if g is None:
-                    host[j, 0] = 0
                     continue
                 if g.dtype != torch.float32 or not g.is_contiguous():
                     raise _lib.AptaiHipError("aptai_amd.optim.Adam needs contiguous fp32 gradients")
                 st["step"] += 1
-                host[j, 0] = g.data_ptr()
-                host[j, 1] = st["step"]
-                any_grad = True
-            if not any_grad:
+                plane = 1 if id(p) in early_ids else 0
+                host[plane, j, 0] = g.data_ptr()
+                host[plane, j, 1] = st["step"]
+                any_early |= plane == 1
+                any_late |= plane == 0
+            if not (any_late or any_early):
                 continue
             t["dyn_dev"].copy_(t["ring"][slot], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(stream)
             t["events"][slot] = ev
-            b1, b2 = group["betas"]
-            _lib.call("aptai_adam_multi", t["table"].data_ptr(), t["dyn_dev"].data_ptr(), len(params), t["max_n"], float(group["lr"]),
-                      float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), stream.cuda_stream)
+            self._pending.append((t, group, any_late))
+
+    def _launch(self, t, group, plane: int, r0: int, r1: int, stream) -> None:
+        b1, b2 = group["betas"]
+        _lib.call("aptai_adam_multi", t["table"][r0].data_ptr(), t["dyn_dev"][plane, r0].data_ptr(), r1 - r0, max(t["numels"][r0:r1]),
+                  float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), stream.cuda_stream)
+
+    @torch.no_grad()
+    def launch_early(self, params, stream=None) -> None:
+        """Update `params` (named in prepare(early=...)) now, on `stream`: one launch per parameter group over the row range that
+        spans them (rows in between that were not named `early` carry no gradient pointer in this plane and are skipped)."""
+        stream = stream or torch.cuda.current_stream()
+        ids = {id(p) for p in params}
+        for t, group, _ in self._pending:
+            rows = [j for j, p in enumerate(t["params"]) if id(p) in ids]
+            if rows:
+                self._launch(t, group, 1, min(rows), max(rows) + 1, stream)
+
+    @torch.no_grad()
+    def finish(self, stream=None) -> None:
+        """Update every parameter that has a gradient and was not named `early`."""
+        stream = stream or torch.cuda.current_stream()
+        for t, group, any_late in self._pending:
+            if any_late:
+                self._launch(t, group, 0, 0, len(t["params"]), stream)
+        self._pending = []
         for plan in self._plans:                    # the copies of every parameter that had a gradient are fresh now;
             plan.optimizer_synced = True            # parameters without one did not move
-        return loss
 
     @property
     def publishes_copies(self) -> bool:

@@ -497,6 +497,13 @@ def main():
         # kernels inside a hipGraph replay cannot be bracketed one by one: re-issue the SAME step eagerly right after the
         # timed region (same model, batch, shapes, regularisers) with the event probe on
         runner.close()
+        # The probe's event pairs time a launch correctly only while the queue is never empty (an idle queue stamps the start
+        # event at once and the kernel arrives a host call later): ~30 ms of unrelated launches first, so that the host stays
+        # ahead of the GPU for the three host-bound eager steps that follow.
+        plug = [torch.zeros(8192, 8192, device=device, dtype=torch.bfloat16) for _ in range(3)]
+        torch.cuda.synchronize()
+        for _ in range(24):
+            ops.gemm(plug[0], plug[1], 8192, 8192, 8192, out=plug[2])
         probe = ops.GemmProbe(False, False, False)
         ops.set_gemm_probe(probe)
         for _ in range(3):
@@ -504,6 +511,7 @@ def main():
             call()["loss"].backward()
         torch.cuda.synchronize()
         ops.set_gemm_probe(None)
+        del plug
         probe_note = "HIP events around every launch of 3 eager re-runs of the same step right after the timed region"
     if world > 1:
         t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)

@@ -405,3 +405,43 @@ def test_bucketed_runner_cache_is_bounded_and_eviction_changes_nothing():
             assert runner.evictions == (0 if cap == 8 else 3), runner.evictions
         assert sum("captured shape" in l for l in lines) == (2 if cap == 8 else 4)
     assert rec[1] == rec[8], rec
+
+
+def test_optimiser_under_the_backward_pass_changes_no_bit(monkeypatch):
+    """APTAI_ADAM_OVERLAP=1 (an experiment, off by default: aptai_amd/graphed.py): each layer's weights and biases are updated on a side
+    stream as soon as the layer's backward segment has finished, the rest in the usual launch at the end of the step (Adam.prepare /
+    launch_early / finish).  Adam is element-wise per parameter, so every parameter, both moments and every step count must equal the
+    one-launch step bit for bit - with LayerDrop on (a skipped layer gets NO update and no step count) and with the compute copies the
+    optimiser publishes (the next step's forward reads them)."""
+    from aptai_amd.config import W2V2Config
+    from aptai_amd.graphed import GraphedAPTAIStep
+    from aptai_amd.optim import Adam
+    from oracle import synth
+    from test_gpu_aptai import _build
+    cfg = W2V2Config.base(num_hidden_layers=3, layerdrop=0.3, vocab_size=46)
+    sd = synth.make_state_dict(synth.aptai_param_shapes(cfg), 0)
+    batch = {k: v.cuda() for k, v in synth.synth_aptai_batch(cfg, 2, 24000, seed=3).items()}
+    rec = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("APTAI_ADAM_OVERLAP", flag)
+        model = _build(cfg, sd, tv_drop=0.1, phn_drop=0.1)
+        model.train()
+        model.wav2vec2._layerdrop_gen = torch.Generator().manual_seed(5)
+        opt = Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-2).publish_to(model)
+        with GraphedAPTAIStep(model, opt, batch) as runner:
+            assert runner.adam_overlap == (flag == "1")
+            runner._salt_gen.seed(7)
+            losses = [runner.step()["loss"].item() for _ in range(5)]
+        torch.cuda.synchronize()
+        rec[flag] = (losses, {n: p.detach().clone() for n, p in model.named_parameters()},
+                     {n: (opt.state[p]["step"], opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone())
+                      for n, p in model.named_parameters() if p in opt.state and len(opt.state[p])})
+    assert rec["0"][0] == rec["1"][0], (rec["0"][0], rec["1"][0])
+    steps = set()
+    for n, p in rec["0"][1].items():
+        assert torch.equal(p, rec["1"][1][n]), n
+    for n, (st, m, v) in rec["0"][2].items():
+        st1, m1, v1 = rec["1"][2][n]
+        assert st == st1 and torch.equal(m, m1) and torch.equal(v, v1), n
+        steps.add(st)
+    assert len(steps) > 1, steps          # LayerDrop did skip a layer in some step: the case the early launches must get right
