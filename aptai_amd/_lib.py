@@ -94,6 +94,7 @@ ARGTYPES = {
     "aptai_bias_act_res_f32": [_P, _I64, _P, _P, _I64, _P, _I64, _I64, _I64, _I, _P, _I64, _P],
     "aptai_softmax_rows_f32": [_P, _P, _I64, _I64, _I64, _P],
     "aptai_softmax_split_f32": [_P, _P, _I64, _I64, _I64, _I, _P, _I64, _P],
+    "aptai_attention_exact_fwd": [_P, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _I, _F, _P],
     "aptai_conv0_fwd_f32": [_P, _I64, _I64, _P, _P, _P, _P, _I, _F, _P, _I64, _I64, _P, _P],
     "aptai_conv0_fwd_split": [_P, _I64, _I64, _P, _P, _P, _P, _I, _F, _P, _I, _I64, _I64, _P, _P],
     "aptai_device_check": [ctypes.c_char_p, _I],

@@ -719,6 +719,235 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnArgs a) {
 #endif
 }
 
+__device__ __forceinline__ uint32_t lds_u32x(const char* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+// ================================================================================== exact-index mode: fused forward (inference)
+// softmax(Q K^T d^-1/2 + key mask) V at fp32-class accuracy from SPLIT bf16 operands (include/aptai_hip.h, aptai_split_f32): every
+// fp32 value is a sum of 2 (f32x3) or 3 (f32x6) bf16 pieces and a product of two values is the 3 (6) leading piece products,
+// accumulated in fp32 by the same 32x32x16 MFMA.  Round 4 ran this as three launches per layer with the fp32 scores (201 MB) and
+// the split probabilities (302 MB) in memory: 88 + 87 + 113 us per layer at 16 x 10 s, a quarter of the exact encoder pass.  Here
+// the scores never leave the registers: same block / wave decomposition as attn_fwd_kernel (4 waves x 32 queries, S^T = K Q^T so
+// a lane owns one query and P^T is the B operand of O^T += V^T P^T as it stands), the probabilities are split IN REGISTERS
+// (p_h = bf16(p), p_m = bf16(p - p_h), ...) and the context leaves as the out-projection's split A operand.
+//
+// qkv: [B*Tp][ld] bf16, thirds Q | K | V of `slots * H` columns each (slots = 3 | 6), head h = K-tile h of its third:
+//   [slot][64].  Q in the activation-side slot order (h h m | h h m m h l), K and V in the weight-side order
+//   (h m h | h m h m l h) - what one aptai_gemm_bf16 launch with APTAI_EPI_SPLIT_OUT and split_out_bcol = H writes.
+// ctx: [B*Tp][ldo] bf16, activation-side split layout ([H/64][slot][64]).
+// K / V tiles (64 keys x 64 features x NPQ pieces each) arrive by LDS-DMA into a 2-deep ring; the tile swizzle (tile_off) sits on
+// the global side of the copy.  The transposing V reads go through inline asm + an explicit lgkmcnt: behind an LDS-DMA the
+// compiler puts vmcnt(0) in front of every ds_read_tr builtin (gemm_common.h), which would serialise the ring.
+struct AttnXArgs {
+    const bf16_t* qkv; long ld;
+    const int* lens;
+    bf16_t* ctx; long ldo;
+    int B, Tp, H, heads, slots;
+    float c;                        // d^-1/2 * log2(e)
+    int xcd_remap;
+};
+
+__device__ __forceinline__ void tr_pair_asm(uint32_t a_lo, uint32_t a_hi, short4v& lo, short4v& hi) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a_lo));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a_hi));
+}
+__device__ __forceinline__ bf16x8 tr_join(const short4v lo, const short4v hi) {
+    return __builtin_bit_cast(bf16x8, (short8v){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+// pieces of 8 fp32 values as packed bf16 fragments: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
+template <int NPQ>
+__device__ __forceinline__ void split8(const float* x, bf16x8 (&out)[NPQ]) {
+    u32x4 hq, mq, lq;
+    float r1[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hq[i] = pack2bf(x[2 * i], x[2 * i + 1]);
+        r1[2 * i] = x[2 * i] - lo_bf(hq[i]);                 // exact in fp32
+        r1[2 * i + 1] = x[2 * i + 1] - hi_bf(hq[i]);
+        mq[i] = pack2bf(r1[2 * i], r1[2 * i + 1]);
+        if (NPQ == 3) lq[i] = pack2bf(r1[2 * i] - lo_bf(mq[i]), r1[2 * i + 1] - hi_bf(mq[i]));
+    }
+    out[0] = __builtin_bit_cast(bf16x8, hq);
+    out[1] = __builtin_bit_cast(bf16x8, mq);
+    if constexpr (NPQ == 3) out[2] = __builtin_bit_cast(bf16x8, lq);
+}
+
+template <int NPQ>                  // distinct pieces per value: 2 (f32x3: 3 products) or 3 (f32x6: 6 products)
+__global__ __launch_bounds__(256, NPQ == 2 ? 2 : 1) void attn_exact_fwd_kernel(AttnXArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char xsmem[];
+    constexpr int TILE = 64 * 128;                              // one piece of one tensor: 64 keys x 64 features
+    constexpr int STAGE = 2 * NPQ * TILE;                       // K pieces, then V pieces
+    constexpr int NPROD = NPQ == 2 ? 3 : 6;
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};       // (activation piece, weight piece) of product i
+    constexpr int ASLOT[3] = {0, 2, 5}, BSLOT[3] = {0, 1, 4};                     // where piece h / m / l sits in each slot order
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int nt = gridDim.x, total = nt * gridDim.y * gridDim.z;
+    int L = blockIdx.x + nt * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (a.xcd_remap && (total & 7) == 0) L = (L & 7) * (total >> 3) + (L >> 3);   // all query tiles of a (utterance, head) on one XCD
+    const int tile_x = L % nt, grp = L / nt, hd = grp % (int)gridDim.y, b = grp / (int)gridDim.y;
+    const int q0 = tile_x * 128 + wave * 32;
+    int len = a.lens[b];
+    len = len < 1 ? 1 : (len > a.Tp ? a.Tp : len);
+    const int ntiles = (len + 63) >> 6;
+    const long rowbase = (long)b * a.Tp, third = (long)a.slots * a.H;
+    const int q = q0 + (lane & 31);
+    const bf16_t* Qg = a.qkv + (rowbase + q) * a.ld + (long)hd * (HD * a.slots);
+    const bf16_t* Kg = a.qkv + rowbase * a.ld + third + (long)hd * (HD * a.slots);
+    const bf16_t* Vg = Kg + third;
+    const LaneOffs lo = lane_offs(lane);
+
+    bf16x8 qf[NPQ][4];
+#pragma unroll
+    for (int i = 0; i < NPQ; ++i)
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) qf[i][ds] = *(const bf16x8*)(Qg + ASLOT[i] * 64 + ds * 16 + h * 8);
+
+    // LDS-DMA staging: instruction `it` of a piece fills LDS bytes [(it * 256 + tid) * 16, +16) of its tile = (row, chunk') of the
+    // swizzled layout, i.e. global chunk chunk' ^ tile_swz(row) of that row
+    long goff[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int cid = it * 256 + tid, row = cid >> 3, cp = cid & 7;
+        goff[it] = (long)row * a.ld + ((cp ^ tile_swz(row)) << 3);
+    }
+    const long tile_stride = 64 * a.ld;
+    auto issue = [&](int t) {
+        char* dst = xsmem + (t & 1) * STAGE + wave * 1024;      // wave-uniform; the hardware adds lane * 16
+        const bf16_t* kt = Kg + (long)t * tile_stride;
+        const bf16_t* vt = Vg + (long)t * tile_stride;
+#pragma unroll
+        for (int j = 0; j < NPQ; ++j)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(kt + BSLOT[j] * 64 + goff[it]), LDS_PTR(dst + j * TILE + it * 4096), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(vt + BSLOT[j] * 64 + goff[it]), LDS_PTR(dst + (NPQ + j) * TILE + it * 4096), 16, 0, 0);
+            }
+    };
+
+    f32x16 oT[2];
+    oT[0] = (f32x16)(0.f);
+    oT[1] = (f32x16)(0.f);
+    float ref = 0.f, l_run = 0.f;
+    const float c = a.c;
+    issue(0);
+
+    auto tile = [&](auto first_flag, auto mask_flag, const int t) {
+        constexpr bool FIRST = decltype(first_flag)::value, MASK = decltype(mask_flag)::value;
+        const char* sK = xsmem + (t & 1) * STAGE;
+        const char* sV = sK + NPQ * TILE;
+        const uint32_t vbase = lds_u32x(sV);
+        const int kbase = t * 64;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+            // V^T fragments of this half's 32 keys, every piece: issued first, they land under the S^T products
+            short4v vl[NPQ][2][2], vh[NPQ][2][2];
+#pragma unroll
+            for (int j = 0; j < NPQ; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        tr_pair_asm(vbase + (uint32_t)(j * TILE + (2 * kt2 + s) * 2048 + lo.tr[dt][0]),
+                                    vbase + (uint32_t)(j * TILE + (2 * kt2 + s) * 2048 + lo.tr[dt][1]), vl[j][s][dt], vh[j][s][dt]);
+            // S^T = sum over the piece products of K_piece Q_piece^T: keys (kt2 * 32 + acc_row) x queries (lane & 31)
+            f32x16 sT = (f32x16)(0.f);
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                bf16x8 kfr[NPQ];
+#pragma unroll
+                for (int j = 0; j < NPQ; ++j) kfr[j] = rd_row(sK + j * TILE, lo, kt2, ds);
+#pragma unroll
+                for (int pr = NPROD - 1; pr >= 0; --pr)          // smallest products first
+                    sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[PB[pr]], qf[PA[pr]][ds], sT, 0, 0, 0);
+            }
+            if (MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + kt2 * 32 + acc_row(r, h) >= len) sT[r] = -INFINITY;
+            }
+            if (FIRST && kt2 == 0) {                            // key 0 is valid: the maximum of the first 32 keys is finite
+                float mt = sT[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sT[r]);
+                mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+                ref = fmaf(mt, c, REF_HEADROOM);
+            }
+            float x[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { x[r] = fast_exp2(fmaf(sT[r], c, -ref)); psum += x[r]; }
+            bf16x8 pf[2][NPQ];
+            split8<NPQ>(&x[0], pf[0]);
+            split8<NPQ>(&x[8], pf[1]);
+            // every V fragment of the half is back (LDS returns in order; the "+v" operands keep the consumers behind the wait)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < NPQ; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    asm volatile("" : "+v"(vl[j][s][0]), "+v"(vh[j][s][0]), "+v"(vl[j][s][1]), "+v"(vh[j][s][1]));
+            // O^T += sum over the piece products of V_piece^T P_piece^T: 2 k-steps of 16 keys
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int pr = NPROD - 1; pr >= 0; --pr)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vl[PB[pr]][s][dt], vh[PB[pr]][s][dt]), pf[s][PA[pr]],
+                                                                         oT[dt], 0, 0, 0);
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run += psum;
+        // the reference moves (by an exact power of two) only when a row sum says some p passed 2^14 times the level of the maximum
+        // it was taken from: see attn_fwd_kernel
+        if (!FIRST && __builtin_amdgcn_ballot_w64(!(psum <= REF_SUM_LIMIT))) {
+            if (!(psum <= REF_SUM_LIMIT)) {
+                const float e = floorf(fast_log2(psum)) + REF_HEADROOM;
+                const float sc = fast_exp2(-e);
+                ref += e;
+                l_run *= sc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oT[0][r] *= sc; oT[1][r] *= sc; }
+            }
+        }
+    };
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's pieces of tile t (and its Q fragments) have landed
+        __syncthreads();                                        // ... everyone's; and everyone has finished reading buffer (t + 1) & 1
+        if (t + 1 < ntiles) issue(t + 1);                       // flies under this tile's products
+        const bool last = t + 1 == ntiles;
+        if (t == 0) { if (last) tile(Flag<true>{}, Flag<true>{}, 0); else tile(Flag<true>{}, Flag<false>{}, 0); }
+        else if (last) tile(Flag<false>{}, Flag<true>{}, t);
+        else tile(Flag<false>{}, Flag<false>{}, t);
+    }
+    __syncthreads();                                           // the ring becomes the epilogue staging area
+    const float inv = 1.0f / l_run;
+    // context -> pieces -> the activation-side slots of this head's K-tile, through the wave's staging area as whole 128-byte rows
+    f32x16 pc[3][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float o = oT[dt][r] * inv;
+            const float hh = bf_round(o), r1 = o - hh, mm = bf_round(r1);
+            pc[0][dt][r] = hh;
+            pc[1][dt][r] = mm;
+            pc[2][dt][r] = NPQ == 3 ? bf_round(r1 - mm) : 0.f;
+        }
+    char* sw = xsmem + wave * (32 * OUT_PITCH);
+    bf16_t* dst = a.ctx + (rowbase + q0) * a.ldo + (long)hd * (HD * a.slots);
+    // activation-side order: h h m | h h m m h l
+    store_rows_bf16(sw, pc[0], 1.0f, dst, a.ldo, lane);
+    store_rows_bf16(sw, pc[0], 1.0f, dst + 64, a.ldo, lane);
+    store_rows_bf16(sw, pc[1], 1.0f, dst + 128, a.ldo, lane);
+    if constexpr (NPQ == 3) {
+        store_rows_bf16(sw, pc[1], 1.0f, dst + 192, a.ldo, lane);
+        store_rows_bf16(sw, pc[0], 1.0f, dst + 256, a.ldo, lane);
+        store_rows_bf16(sw, pc[2], 1.0f, dst + 320, a.ldo, lane);
+    }
+}
+
 int fill_args(AttnArgs& a, const char* who, const void* qkv, const int32_t* lens, int64_t B, int64_t Tp, int64_t H,
               int64_t heads, float scale, float dropout_p, uint64_t seed, int q_prescaled, const void* stream) {
     APTAI_REQUIRE(qkv && lens, "%s: null pointer", who);
@@ -789,5 +1018,36 @@ extern "C" int aptai_attention_bwd(const void* qkv, const int32_t* lens, const v
         APTAI_LAUNCH(attn_bwd_dkdv_kernel<false>, grid, dim3(256), 0, stream, a);
     }
     APTAI_CHECK_LAUNCH("attn_bwd_dkdv_kernel");
+    return APTAI_OK;
+}
+
+extern "C" int aptai_attention_exact_fwd(const void* qkv_split, int64_t ld, const int32_t* lens, void* ctx_split, int64_t ldo, int64_t B,
+                                         int64_t Tp, int64_t H, int64_t heads, int pieces, float scale, void* stream_) {
+    APTAI_REQUIRE(qkv_split && lens && ctx_split, "aptai_attention_exact_fwd: null pointer");
+    APTAI_REQUIRE(B > 0 && Tp > 0 && Tp % 128 == 0, "aptai_attention_exact_fwd: frames per utterance (%ld) must be a positive multiple of 128", (long)Tp);
+    APTAI_REQUIRE(heads > 0 && H == heads * HD, "aptai_attention_exact_fwd: head_dim must be 64 (H=%ld heads=%ld)", (long)H, (long)heads);
+    APTAI_REQUIRE(pieces == 3 || pieces == 6, "aptai_attention_exact_fwd: pieces must be 3 (f32x3) or 6 (f32x6)");
+    APTAI_REQUIRE(ld >= 3 * pieces * H && ld % 8 == 0 && ldo >= pieces * H && ldo % 8 == 0, "aptai_attention_exact_fwd: row pitches (ld=%ld, ldo=%ld) too small "
+                  "for %d slots of H=%ld or not a multiple of 8", (long)ld, (long)ldo, pieces, (long)H);
+    APTAI_REQUIRE((uintptr_t)qkv_split % 16 == 0 && (uintptr_t)ctx_split % 16 == 0, "aptai_attention_exact_fwd: operands must be 16-byte aligned");
+    AttnXArgs a;
+    a.qkv = (const bf16_t*)qkv_split; a.ld = ld; a.lens = lens; a.ctx = (bf16_t*)ctx_split; a.ldo = ldo;
+    a.B = (int)B; a.Tp = (int)Tp; a.H = (int)H; a.heads = (int)heads; a.slots = pieces;
+    a.c = scale * LOG2E;
+    static const int remap = getenv("APTAI_ATTN_XCD_REMAP") ? atoi(getenv("APTAI_ATTN_XCD_REMAP")) : 1;
+    a.xcd_remap = remap;
+    const dim3 grid((unsigned)(Tp / 128), (unsigned)heads, (unsigned)B);
+    if (pieces == 3) {
+        constexpr int smem = 2 * 2 * 2 * 64 * 128;              // 2 stages x (K, V) x 2 pieces x 8 KiB
+        static const hipError_t attr = hipFuncSetAttribute((const void*)attn_exact_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        APTAI_REQUIRE(attr == hipSuccess, "aptai_attention_exact_fwd: cannot reserve %d bytes of LDS", smem);
+        APTAI_LAUNCH(attn_exact_fwd_kernel<2>, grid, dim3(256), smem, (hipStream_t)stream_, a);
+    } else {
+        constexpr int smem = 2 * 2 * 3 * 64 * 128;
+        static const hipError_t attr = hipFuncSetAttribute((const void*)attn_exact_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        APTAI_REQUIRE(attr == hipSuccess, "aptai_attention_exact_fwd: cannot reserve %d bytes of LDS", smem);
+        APTAI_LAUNCH(attn_exact_fwd_kernel<3>, grid, dim3(256), smem, (hipStream_t)stream_, a);
+    }
+    APTAI_CHECK_LAUNCH("attn_exact_fwd_kernel");
     return APTAI_OK;
 }

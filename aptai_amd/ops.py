@@ -356,6 +356,19 @@ def softmax_split_f32(s32, lens_i32, B, heads, Tp, pieces):
     return out
 
 
+def attention_exact_fwd(qkv_s, lens_i32, B, Tp, H, heads, pieces, scale, out=None):
+    """Fused attention core of the exact-index mode (aptai_attention_exact_fwd): qkv_s bf16 [B Tp][3 pieces H] split Q | K | V as the
+    q|k|v projection's split-out epilogue wrote them -> the context as split pieces [B Tp][pieces H] (the out-projection's A operand)."""
+    _dev(qkv_s, lens_i32, out)
+    if qkv_s.dtype != torch.bfloat16 or qkv_s.stride(1) != 1 or qkv_s.shape[0] != B * Tp or qkv_s.shape[1] != 3 * pieces * H:
+        raise _lib.AptaiHipError("attention_exact_fwd: qkv_s must be bf16 [B Tp][3 pieces H] with unit column stride")
+    if out is None:
+        out = torch.empty((B * Tp, pieces * H), device=qkv_s.device, dtype=torch.bfloat16)
+    _lib.call("aptai_attention_exact_fwd", qkv_s.data_ptr(), qkv_s.stride(0), lens_i32.data_ptr(), out.data_ptr(), out.stride(0), B, Tp, H,
+              heads, pieces, float(scale), _stream())
+    return out
+
+
 def conv0_fwd_f32(audio, weight, bias, gamma, beta, mode, out32, T_real, T_alloc, stats, eps=1e-5):
     _dev(audio, weight, bias, gamma, beta, out32, stats)
     B, S = audio.shape

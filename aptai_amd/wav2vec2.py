@@ -907,8 +907,7 @@ class Wav2Vec2Model(nn.Module):
             for i in range(len(self.encoder.layers)):
                 p = [t.detach() for t in self._layer_params(i)]
                 w.layers.append(SimpleNamespace(
-                    wqk=ops.split_f32(torch.cat(p[0:2]).contiguous(), P, weight_side=True), bqk=torch.cat(p[3:5]).contiguous(),
-                    wv=ops.split_f32(p[2].contiguous(), P, weight_side=True), bv=p[5].contiguous(),
+                    wqkv=ops.split_f32(torch.cat(p[0:3]).contiguous(), P, weight_side=True), bqkv=torch.cat(p[3:6]).contiguous(),
                     wo=ops.split_f32(p[6].contiguous(), P, weight_side=True), bo=p[7],
                     w1=ops.split_f32(p[8].contiguous(), P, weight_side=True), b1=p[9],
                     w2=ops.split_f32(p[10].contiguous(), P, weight_side=True), b2=p[11]))
@@ -917,33 +916,21 @@ class Wav2Vec2Model(nn.Module):
 
     def _exact_attention(self, a_s, w, lens_i32, g, P=3):
         """q|k|v projection + softmax(Q K^T / sqrt(d) + key mask) V per head (HF:438-548) at fp32-class accuracy, from the layer input's
-        split pieces `a_s` [M][P H].  Round 4: every product is a SPLIT-OPERAND bf16 GEMM and no fp32 tensor but the scores is stored.
-          * q|k projection: one launch, its result leaves already split (APTAI_EPI_SPLIT_OUT): Q in the activation-side piece order, K
-            (columns >= H, `split_out_bcol`) in the weight-side order - the two operands of Q K^T.  Per head the 64 feature columns are
-            exactly one K-tile of the split layout, so head h is the column block [64 P h, 64 P (h + 1)) and the batch strides of
-            aptai_gemm_bf16 walk heads and utterances: nothing is re-packed;
-          * V is projected TRANSPOSED, V^T [H][M] = W_v . X^T (the weight as the row operand, its Linear bias along the rows:
-            APTAI_EPI_BIAS_ROW), and leaves split along the key axis in the weight-side order: the B operand of P . V as it is;
-          * scores [B][heads][Tp][Tp] fp32 -> aptai_softmax_split_f32 -> P . V, whose result leaves as the out-projection's split A.
-        (Round 3: 24 launches per layer on the fp32 matrix instruction, 10 of the mode's 27 ms.)"""
+        split pieces `a_s` [M][P H], in TWO launches:
+          * the q|k|v projection as one split-operand GEMM whose result leaves already split (APTAI_EPI_SPLIT_OUT): Q in the
+            activation-side piece order, K and V (columns >= H, `split_out_bcol`) in the weight-side order.  Per head the 64 feature
+            columns are exactly one K-tile of the split layout, so head h is the column block [64 P h, 64 P (h + 1)) of its third;
+          * aptai_attention_exact_fwd: scores, masked softmax, the split of the probabilities and P . V in one kernel - every product the
+            3 (6) leading bf16 piece products in fp32, nothing but the context (as the out-projection's split A operand) stored.
+        (Round 3: 24 launches per layer on the fp32 matrix instruction, 10 of the mode's 27 ms; round 4 first ran the scores, the softmax and
+        P . V as three launches with the fp32 scores and the split probabilities in memory: 0.29 ms of the layer's 1.0.)"""
         cfg = self.config
         H, heads, B, Tp, M = cfg.hidden_size, cfg.num_attention_heads, g.B, g.Tp, g.M
         d = H // heads
         if d != 64:
             raise NotImplementedError("the exact attention is built for head_dim 64 (one K-tile of the split layout per head)")
-        dev = a_s.device
-        qks = ops.gemm_split(a_s, w.wqk, M, 2 * H, H, P, bias=w.bqk, split_out=True, split_bcol=H)          # [M][P 2H]: Q | K
-        vts = torch.empty((H, P * M), device=dev, dtype=torch.bfloat16)                                      # V^T, split along the keys
-        ops.gemm(w.wv, a_s, H, M, P * H, out=vts, ldc=P * M, out_f32=True, tile=128, bias_row=w.bv, split_out=P, split_bcol=0)
-        s32 = torch.empty((B, heads, Tp, Tp), device=dev, dtype=torch.float32)
-        ops.gemm(qks, qks[:, P * H:], Tp, Tp, P * d, lda=2 * P * H, ldb=2 * P * H, out=s32, ldc=Tp, out_f32=True, alpha=d ** -0.5, tile=128,
-                 batch=dict(outer=B, inner=heads, a=(Tp * 2 * P * H, P * d), b=(Tp * 2 * P * H, P * d), c=(heads * Tp * Tp, Tp * Tp)))
-        ps = ops.softmax_split_f32(s32, lens_i32, B, heads, Tp, P)              # [B heads Tp][P Tp]: softmax + split in one pass
-        # the context leaves as the out-projection's split A operand (head h = K-tile h of the split layout: column block h * 64 P)
-        ctx_s = torch.empty((M, P * H), device=dev, dtype=torch.bfloat16)
-        ops.gemm(ps, vts, Tp, d, P * Tp, lda=P * Tp, ldb=P * M, out=ctx_s, ldc=P * H, out_f32=True, tile=128, split_out=P,
-                 batch=dict(outer=B, inner=heads, a=(heads * Tp * P * Tp, Tp * P * Tp), b=(Tp * P, d * P * M), c=(Tp * P * H, P * d)))
-        return ctx_s
+        qkvs = ops.gemm_split(a_s, w.wqkv, M, 3 * H, H, P, bias=w.bqkv, split_out=True, split_bcol=H)          # [M][P 3H]: Q | K | V
+        return ops.attention_exact_fwd(qkvs, lens_i32, B, Tp, H, heads, P, d ** -0.5)
 
     def _forward_exact(self, audio, g, lens_i32, P, output_hidden_states):
         """The whole encoder in eval mode at fp32-class accuracy (set_encoder_precision("f32x3" | "f32x6")).  Returns

@@ -144,6 +144,17 @@ int aptai_softmax_rows_f32(float* s, const int32_t* lens, int64_t B, int64_t hea
  * aptai_split_f32: the fp32 probabilities are never stored).  s fp32 [B][heads][Tp][Tp]; out bf16, row pitch ldo >= pieces * Tp. */
 int aptai_softmax_split_f32(const float* s, const int32_t* lens, int64_t B, int64_t heads, int64_t Tp, int pieces, void* out, int64_t ldo,
                             void* stream);
+/* The whole attention core of the exact-index mode in ONE launch: softmax(Q K^T * scale + key mask) V per (utterance, head), every product
+ * as the 3 (pieces = 3, "f32x3") or 6 (pieces = 6, "f32x6") leading bf16 piece products accumulated in fp32, the scores and probabilities
+ * never stored (replaces HF:452-461 on the path of models/force_aptai.py:148-161 whose argmax indices must be the reference's; round 4's
+ * three launches - aptai_gemm_bf16 scores, aptai_softmax_split_f32, aptai_gemm_bf16 P . V - moved ~0.8 GB per layer at 16 x 10 s).
+ * qkv_split bf16 [B*Tp][ld >= 3 * pieces * H]: thirds Q | K | V of pieces * H columns, head h = columns [64 * pieces * h, +64 * pieces)
+ * of its third as [slot][64]; Q in the activation-side slot order, K and V in the weight-side order - what one aptai_gemm_bf16 launch with
+ * APTAI_EPI_SPLIT_OUT, split_out_pieces = pieces and split_out_bcol = H writes for the concatenated q|k|v weight.  lens int32 [B]: keys
+ * >= lens[b] get probability 0, query rows beyond it are computed like the reference's.  ctx_split bf16 [B*Tp][ldo >= pieces * H] in the
+ * activation-side split layout: the out-projection's A operand.  Tp % 128 == 0, head_dim 64.  Inference only (no dropout, no backward). */
+int aptai_attention_exact_fwd(const void* qkv_split, int64_t ld, const int32_t* lens, void* ctx_split, int64_t ldo, int64_t B, int64_t Tp,
+                              int64_t H, int64_t heads, int pieces, float scale, void* stream);
 /* Conv1d(1,512,10,5) + GroupNorm / LayerNorm + erf GELU with FP32 output [B][T_alloc][512] (HF:260-323); `stats` = the (mean, rstd)
  * block [B][2][512] of aptai_conv0_fwd in group mode (mode 0), unused in layer mode (mode 1). */
 int aptai_conv0_fwd_f32(const float* audio, int64_t B, int64_t S, const float* weight, const float* bias, const float* gamma,

@@ -206,3 +206,69 @@ def test_split_out_epilogue_equals_gemm_then_split(P):
         assert torch.equal(got.view(torch.int16), ref2.view(torch.int16)), tile
     with pytest.raises(Exception):
         ops.gemm(a2, w2, M2, N2, P * K, out_f32=True, tile=64, split_out=P)
+
+
+def _unsplit(xs: torch.Tensor, P: int, weight_side: bool = False) -> torch.Tensor:
+    """Sum of the distinct pieces of a split tensor [rows][cols P] (layout [cols / 64][slot][64]) in float64."""
+    rows = xs.shape[0]
+    t = xs.view(rows, -1, P, 64).double()
+    slots = ((0, 1, 4) if weight_side else (0, 2, 5))[: (2 if P == 3 else 3)]
+    return sum(t[:, :, s] for s in slots).reshape(rows, -1)
+
+
+@pytest.mark.parametrize("P,tol", [(3, 1e-4), (6, 8e-6)])
+def test_fused_exact_attention_against_float64_and_the_three_launch_form(P, tol):
+    """aptai_attention_exact_fwd (round 4): scores, key-masked softmax, the split of the probabilities and P . V in one kernel.  Checked
+    (a) against softmax(Q K^T / 8 + mask) V in float64 computed from the SAME split operands (what the pieces represent), ragged lengths
+    incl. one utterance shorter than a key tile and one that fills Tp, scores with a spread of e^+-12 so the reference point of the
+    running softmax is exercised; (b) against the three launches it replaces (aptai_gemm_bf16 scores -> aptai_softmax_split_f32 ->
+    aptai_gemm_bf16 P . V) - same accuracy class; (c) slot duplication of the output layout bit for bit."""
+    from aptai_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, heads, Tp, d = 3, 2, 256, 64
+    H, M = heads * d, B * Tp
+    lens = torch.tensor([256, 37, 190], dtype=torch.int32).cuda()
+    q32 = (torch.randn(M, H, generator=g) * 3.0).cuda()
+    k32 = (torch.randn(M, H, generator=g) * 3.0).cuda()
+    v32 = torch.randn(M, H, generator=g).cuda()
+    k32[5] *= 4.0                                           # one dominant key per utterance-0 head: a sharp row
+    qkvs = torch.cat([ops.split_f32(q32, P), ops.split_f32(k32, P, weight_side=True), ops.split_f32(v32, P, weight_side=True)], dim=1).contiguous()
+    ctx_s = ops.attention_exact_fwd(qkvs, lens, B, Tp, H, heads, P, d ** -0.5)
+    torch.cuda.synchronize()
+    assert ctx_s.shape == (M, P * H) and ctx_s.dtype == torch.bfloat16
+    got = _unsplit(ctx_s, P).view(B, Tp, heads, d)
+    q64 = _unsplit(qkvs[:, :P * H].contiguous(), P).view(B, Tp, heads, d)
+    k64 = _unsplit(qkvs[:, P * H:2 * P * H].contiguous(), P, True).view(B, Tp, heads, d)
+    v64 = _unsplit(qkvs[:, 2 * P * H:].contiguous(), P, True).view(B, Tp, heads, d)
+    s = torch.einsum("bqhd,bkhd->bhqk", q64, k64) * d ** -0.5
+    key = torch.arange(Tp, device="cuda")[None, None, None, :] >= lens.long()[:, None, None, None]
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s.masked_fill(key, float("-inf")), -1), v64)
+    err = ((got - ref).abs().amax() / ref.abs().amax()).item()
+    row_err = ((got - ref).abs().amax(-1) / ref.abs().amax(-1).clamp_min(1e-3)).amax().item()
+    print(f"[exact] fused attention, {P} pieces: max deviation {err:.2e} of the largest context value, worst row {row_err:.2e}")
+    # (b) the three-launch form on the same operands
+    s32 = torch.empty((B, heads, Tp, Tp), device="cuda", dtype=torch.float32)
+    ld = 3 * P * H
+    ops.gemm(qkvs, qkvs[:, P * H:], Tp, Tp, P * d, lda=ld, ldb=ld, out=s32, ldc=Tp, out_f32=True, alpha=d ** -0.5, tile=128,
+             batch=dict(outer=B, inner=heads, a=(Tp * ld, P * d), b=(Tp * ld, P * d), c=(heads * Tp * Tp, Tp * Tp)))
+    ps = ops.softmax_split_f32(s32, lens, B, heads, Tp, P)
+    vts = ops.split_f32(v32.view(B, Tp, heads, d).permute(2, 3, 0, 1).reshape(H, M).contiguous(), P, weight_side=True)     # V^T, split along the keys
+    old_s = torch.empty((M, P * H), device="cuda", dtype=torch.bfloat16)
+    ops.gemm(ps, vts, Tp, d, P * Tp, lda=P * Tp, ldb=P * M, out=old_s, ldc=P * H, out_f32=True, tile=128, split_out=P,
+             batch=dict(outer=B, inner=heads, a=(heads * Tp * P * Tp, Tp * P * Tp), b=(Tp * P, d * P * M), c=(Tp * P * H, P * d)))
+    old = _unsplit(old_s, P).view(B, Tp, heads, d)
+    err_old = ((old - ref).abs().amax() / ref.abs().amax()).item()
+    print(f"[exact] three-launch form on the same operands: {err_old:.2e}")
+    assert err <= tol and row_err <= 20 * tol
+    assert err <= max(2 * err_old, tol / 8)
+    # (c) the duplicated slots of the activation-side order (h h m | h h m m h l) carry identical pieces
+    t = ctx_s.view(M, heads, P, 64).view(torch.int16)
+    assert torch.equal(t[:, :, 0], t[:, :, 1])
+    if P == 6:
+        assert torch.equal(t[:, :, 0], t[:, :, 4]) and torch.equal(t[:, :, 2], t[:, :, 3])
+    # refusals
+    with pytest.raises(Exception):
+        ops.attention_exact_fwd(qkvs[:, :-8].contiguous(), lens, B, Tp, H, heads, P, d ** -0.5)
+    with pytest.raises(Exception):
+        _ = __import__("aptai_amd")._lib.call("aptai_attention_exact_fwd", qkvs.data_ptr(), ld, lens.data_ptr(), ctx_s.data_ptr(), P * H, B, 200, H,
+                                              heads, P, 0.125, 0)
