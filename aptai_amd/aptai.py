@@ -162,7 +162,7 @@ class APTAI(nn.Module):
             names = TV_NAMES if self.n_tv == 9 else tuple(f"TV{i}" for i in range(self.n_tv))
             tvs_pred_dict = {n: [row[i] for row in tvs_out] for i, n in enumerate(names)}
             return {
-                'phn_fc_probs': phn_probs.T.squeeze(dim=0).cpu().numpy(),
+                'phn_fc_probs': phn_probs.permute(2, 1, 0).squeeze(dim=0).cpu().numpy(),      # the reference's `.T` on (1, T, C): (C, T, 1)
                 'phn_fc_logits': phn_logits.squeeze(dim=0).cpu().numpy(),
                 'phn_fc_pred': pred.squeeze(dim=0).cpu().numpy(),
                 'tvs_pred': tvs_pred_dict,

@@ -207,6 +207,105 @@ def ctc_best_path(logits: np.ndarray, length: int, blank: int = 0) -> np.ndarray
     return ids[ids != blank].astype(np.int64)
 
 
+# ----------------------------------------------------------------------------- the reference's beam decoder, restated
+def ctc_bracketed_best_path(logits: np.ndarray, length: int, blank: int = 0, sil: int = None):
+    """What the reference's decoder call returns for its settings, in closed form: (tokens int64, timesteps int32).
+
+    models/w2v2_pr.py:144-159 / utility.py:448-471 call torchaudio.models.decoder.ctc_decoder(lexicon=None, lm=None, nbest=1,
+    beam_size=10, beam_threshold=50, log_add=False (default), blank_token='(blank)', sil_token='(...)'): flashlight's
+    lexicon-free decoder.  With no language model and max-merging of equal hypotheses a hypothesis' score is the sum of the emissions
+    along its best alignment, so the prefix of the frame-wise argmax path is the top candidate of every frame, survives every pruning
+    (beam_size >= 1, beam_threshold >= 0) and the first returned hypothesis IS the best path - `ctc_beam_search` below restates the
+    published algorithm and tests/test_cpu_host.py checks the equality on random emissions.  What differs from a plain best-path read-out
+    is the decoder's FRAMING: it starts every hypothesis with the silence token and closes it with another one (decodeBegin /
+    decodeEnd), torchaudio then collapses repeats over that T + 2 long token row and drops blanks, and reports as `timesteps` the row
+    positions where a token starts - so a frame t appears as t + 1, the first silence at 0, the closing one at T + 1, and a silence
+    emitted at the very first / last frame merges with the framing one.  torchaudio is not in the image: *parity unpinned*
+    (SURVEY.md section 8c); the sources restated are flashlight-text LexiconFreeDecoder.cpp and torchaudio/models/decoder/_ctc_decoder.py
+    as published."""
+    ids = np.asarray(logits)[:length].argmax(axis=-1).astype(np.int64)
+    row = ids if sil is None else np.concatenate([[sil], ids, [sil]])
+    keep = np.ones(len(row), dtype=bool)
+    keep[1:] = row[1:] != row[:-1]
+    keep &= row != blank
+    pos = np.nonzero(keep)[0]
+    return row[pos].astype(np.int64), pos.astype(np.int32)
+
+
+def ctc_beam_search(emissions: np.ndarray, blank: int, sil: int, beam_size: int = 10, beam_size_token: int = None,
+                    beam_threshold: float = 50.0, log_add: bool = False, nbest: int = 1, sil_score: float = 0.0):
+    """flashlight's lexicon-free CTC beam search without a language model, restated from the published sources (see
+    ctc_bracketed_best_path), plus torchaudio's read-out of each hypothesis.  emissions [T][N] (any scores: the reference feeds raw
+    logits).  Returns the `nbest` best hypotheses, best first, as (tokens int64, timesteps int32, score float).
+
+    State of a hypothesis = (token history, last token, last-was-blank); per frame every hypothesis is extended by every token (the
+    `beam_size_token` best of the frame when given): a non-blank token that differs from the last one, or follows a blank, EXTENDS
+    the history; a blank keeps it and sets the flag; a repeat keeps it.  Candidates below best - beam_threshold are dropped,
+    candidates of equal state are merged (max, or log-add with `log_add`), the `beam_size` best survive.  Test infrastructure for the
+    closed form above and the opt-in `Wav2Vec2_PR.decoder = "flashlight"`: O(T beam N) Python, not a product hot path."""
+    em = np.asarray(emissions, dtype=np.float64)
+    T, N = em.shape
+    k_tok = N if beam_size_token is None else min(int(beam_size_token), N)
+    trie = {}                                      # (history id, token) -> history id (the ZeroLM state tree)
+
+    def child(hist, tok):
+        key = (hist, tok)
+        if key not in trie:
+            trie[key] = len(trie) + 1
+        return trie[key]
+
+    # a hypothesis: (score, history id, parent hypothesis or None, token, last-was-blank)
+    hyps = [(0.0, 0, None, sil, False)]
+    for t in range(T):
+        order = np.argsort(-em[t], kind="stable")[:k_tok] if k_tok < N else np.arange(N)
+        cands, best = [], -np.inf
+        for h in hyps:
+            hs, hist, _, prev, prev_blank = h
+            for n in order:
+                n = int(n)
+                sc = hs + em[t, n] + (sil_score if n == sil else 0.0)
+                if n != blank and (n != prev or prev_blank):
+                    c = (sc, child(hist, n), h, n, False)
+                elif n == blank:
+                    c = (sc, hist, h, n, True)
+                else:
+                    c = (sc, hist, h, n, False)
+                best = max(best, sc)
+                if sc >= best - beam_threshold:
+                    cands.append(c)
+        hyps = _merge_and_prune(cands, best - beam_threshold, beam_size, log_add)
+    cands = [(h[0], h[1], h, sil, False) for h in hyps]
+    final = _merge_and_prune(cands, max(c[0] for c in cands) - beam_threshold, beam_size, log_add)
+    out = []
+    for h in final[:nbest]:
+        row, node = [], h
+        while node is not None:
+            row.append(node[3])
+            node = node[2]
+        row = np.asarray(row[::-1], dtype=np.int64)          # T + 2 tokens: opening silence, one per frame, closing silence
+        keep = np.ones(len(row), dtype=bool)
+        keep[1:] = row[1:] != row[:-1]
+        keep &= row != blank
+        pos = np.nonzero(keep)[0]
+        out.append((row[pos], pos.astype(np.int32), float(h[0])))
+    return out
+
+
+def _merge_and_prune(cands, floor, beam_size, log_add):
+    cands = [c for c in cands if c[0] >= floor]
+    cands.sort(key=lambda c: (c[1], c[3], c[4], -c[0]))          # equal states adjacent, the best of each first
+    merged = []
+    for c in cands:
+        if merged and merged[-1][1] == c[1] and merged[-1][3] == c[3] and merged[-1][4] == c[4]:
+            if log_add:
+                m = merged[-1]
+                merged[-1] = (float(np.logaddexp(m[0], c[0])),) + m[1:]
+            continue
+        merged.append(c)
+    merged.sort(key=lambda c: -c[0])
+    return merged[:beam_size]
+
+
 # ----------------------------------------------------------------------------- target preparation (SURVEY.md §8f-4)
 def interpolate_signal(org_sig, tar_len: int) -> np.ndarray:
     """Linear resampling of a [frames] or [frames][channels] track to ``tar_len`` points that span the same time range

@@ -4,6 +4,12 @@ Same constructor ``(pretrain_cfg, cache_dir, huggingface_model_id, vocab)``, ``f
 phoneme_labels)`` dict, inference helpers and state-dict keys (``wav2vec2.*``, ``pr_head.*``).  The torchaudio /
 flashlight beam-search decoder the reference calls (models/w2v2_pr.py:143-159) is not in the image: decoding here is
 the best path (frame argmax on the device, collapse + blank removal on the host) — *parity unpinned* (SURVEY.md §8c).
+
+``model.decoder = "flashlight"`` (opt-in) returns what the published decoder sources say that call returns for the
+reference's settings: the same best path FRAMED by the decoder's opening / closing silence token ``'(...)'``, timesteps as
+positions in the framed token row (hostlogic.ctc_bracketed_best_path; hostlogic.ctc_beam_search restates the search itself
+and the CPU tests check the two against each other).  It is not the default because nothing in this image can pin it and
+the reference-generated fixtures under tests/golden were made with a plain best-path stand-in.
 """
 from __future__ import annotations
 
@@ -138,16 +144,42 @@ class Wav2Vec2_PR(nn.Module):
     def _blank(self) -> int:
         return int(self.vocab.get('(blank)', 0)) if isinstance(self.vocab, dict) else 0
 
+    decoder = "best_path"           # or "flashlight": framed like the reference's torchaudio decoder call (module docstring)
+
+    def _sil(self):
+        if self.decoder == "best_path":
+            return None
+        if self.decoder != "flashlight":
+            raise ValueError(f"Wav2Vec2_PR.decoder must be 'best_path' or 'flashlight', not {self.decoder!r}")
+        if not (isinstance(self.vocab, dict) and '(...)' in self.vocab):
+            raise ValueError("decoder = 'flashlight' needs the silence token '(...)' in the vocabulary (models/w2v2_pr.py:153)")
+        return int(self.vocab['(...)'])
+
     def _decode_device(self, out, max_n: int):
         """Best-path decode on the device (aptai_ctc_greedy_decode): (ids int32 [B][max_n] zero-padded, n int32 [B]) over ALL
         frames of the padded batch, like the reference's decoder call (models/w2v2_pr.py:155 passes no lengths).  Nothing
-        here synchronises host and device."""
+        here synchronises host and device.  decoder = "flashlight": the sequence is framed by the silence token on the device
+        (hostlogic.ctc_bracketed_best_path: prepended / appended unless the first / last frame's own token is the silence)."""
         g, full = out._geom, out._logits_full
-        return ops.ctc_greedy_decode(full, full.shape[1], g.Tp, g.B, g.T, self.pr_head.weight.shape[0], self._blank(), max_n)
+        V = self.pr_head.weight.shape[0]
+        ids, n = ops.ctc_greedy_decode(full, full.shape[1], g.Tp, g.B, g.T, V, self._blank(), max_n)
+        sil = self._sil()
+        if sil is None:
+            return ids, n
+        ends = full.view(g.B, g.Tp, -1)[:, [0, g.T - 1], :V].argmax(dim=-1)
+        front, back = (ends[:, :1] != sil).to(torch.int32), (ends[:, 1:] != sil).to(torch.int32)          # [B][1]
+        pos = torch.arange(max_n, device=ids.device, dtype=torch.int32)[None]
+        n1 = n[:, None]
+        framed = torch.gather(ids, 1, (pos - front).clamp(min=0).long())
+        framed = torch.where(pos < front, sil, framed)
+        framed = torch.where((pos == n1 + front) & (back == 1), sil, framed)
+        total = n1 + front + back
+        framed = torch.where(pos >= total, 0, framed).to(torch.int32)
+        return framed.contiguous(), total.clamp(max=max_n).view(-1).to(torch.int32)
 
     def _decode(self, out):
         """Decoded id lists of the batch: the device decode + ONE host transfer."""
-        ids, n = self._decode_device(out, out._geom.T)
+        ids, n = self._decode_device(out, out._geom.T + 2)
         ids, n = ids.cpu().numpy(), n.cpu().numpy()
         return [ids[b, :n[b]].astype(np.int64) for b in range(len(n))]
 
@@ -212,12 +244,8 @@ class Wav2Vec2_PR(nn.Module):
         with torch.no_grad():
             wav, wav_input, wav_len = self._wav(wav)
             _, logits = self._logits_eval(wav_input, wav_len)
-            ids = logits[0].argmax(dim=-1).cpu().numpy()
             frame_sec_ratio = len(wav) / logits.size(1) / 16000
-            keep = np.ones(len(ids), dtype=bool)
-            keep[1:] = ids[1:] != ids[:-1]
-            ts = np.nonzero(keep & (ids != self._blank()))[0]
-            idx = ids[ts]
+            idx, ts = hostlogic.ctc_bracketed_best_path(logits[0].cpu().numpy(), logits.size(1), self._blank(), self._sil())
             inv = {v: k for k, v in vocab.items()}
             return {'phn_seq_idx': idx, 'phn_seq_ipa': [inv.get(int(i), '?') for i in idx],
                     'phn_seq_dur': [t * frame_sec_ratio for t in ts]}

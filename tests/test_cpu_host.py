@@ -252,3 +252,68 @@ def test_auto_tile_context_sets_and_restores_the_default_tile():
             assert ops._AUTO_TILE == 0
         assert ops._AUTO_TILE == 128
     assert ops._AUTO_TILE == 0
+
+
+def _history(path, blank, sil):
+    prev, prev_blank, hist = sil, False, []
+    for n in path:
+        if n != blank and (n != prev or prev_blank):
+            hist.append(n)
+        prev_blank = n == blank
+        prev = n
+    return tuple(hist)
+
+
+def test_restated_beam_decoder_merges_like_an_exhaustive_search():
+    """hostlogic.ctc_beam_search restates flashlight's lexicon-free CTC decoder (the reference's torchaudio ctc_decoder call,
+    models/w2v2_pr.py:144-155; the package is absent: PARITY UNPINNED).  With a beam that prunes nothing, its hypotheses must be
+    exactly the distinct token histories of all N^T alignments, each scored with the best alignment (log_add=False, the reference's
+    setting) or the log-sum of its alignments (log_add=True) - pinned against brute-force enumeration."""
+    import itertools
+    rng = np.random.default_rng(1)
+    for _ in range(12):
+        T, N = int(rng.integers(1, 7)), 3
+        blank = int(rng.integers(0, 3))
+        sil = (blank + 1) % 3
+        em = rng.normal(size=(T, N))
+        tot, best = {}, {}
+        for path in itertools.product(range(N), repeat=T):
+            k, sc = _history(path, blank, sil), sum(em[t, p] for t, p in enumerate(path))
+            tot[k] = np.logaddexp(tot.get(k, -np.inf), sc)
+            best[k] = max(best.get(k, -np.inf), sc)
+        for log_add, ref in ((False, best), (True, tot)):
+            res = hostlogic.ctc_beam_search(em, blank, sil, beam_size=10 ** 6, beam_threshold=1e9, log_add=log_add, nbest=10 ** 6)
+            assert len(res) == len(ref)
+            np.testing.assert_allclose(sorted(r[2] for r in res), sorted(ref.values()), rtol=0, atol=1e-12)
+            assert all(res[i][2] >= res[i + 1][2] for i in range(len(res) - 1))
+
+
+def test_reference_decoder_settings_return_the_framed_best_path():
+    """With the reference's settings (no LM, max-merge, beam_size 10, beam_threshold 50) the first hypothesis of the restated beam search
+    is the frame-wise best path FRAMED by the decoder's opening / closing silence tokens, and its timesteps are row positions of the
+    T + 2 long token row (frame t -> t + 1): hostlogic.ctc_bracketed_best_path, the closed form the opt-in
+    Wav2Vec2_PR.decoder = "flashlight" uses.  Random emissions incl. silence at the first / last frame (merges with the framing token),
+    narrow beams and a zero threshold."""
+    rng = np.random.default_rng(0)
+    for trial in range(120):
+        T, N = int(rng.integers(1, 25)), int(rng.integers(3, 8))
+        blank = int(rng.integers(0, N))
+        sil = int((blank + 1 + rng.integers(0, N - 1)) % N)
+        em = rng.normal(size=(T, N)) * 3
+        if trial % 3 == 0:
+            em[0, sil] += 10
+        if trial % 4 == 0:
+            em[-1, sil] += 10
+        want_tok, want_ts = hostlogic.ctc_bracketed_best_path(em, T, blank, sil)
+        assert want_tok[0] == sil and want_tok[-1] == sil and want_ts[0] == 0
+        for beam, thr in ((1, 50.0), (3, 50.0), (10, 50.0), (10, 0.0)):
+            tok, ts, score = hostlogic.ctc_beam_search(em, blank, sil, beam_size=beam, beam_threshold=thr)[0]
+            assert np.array_equal(tok, want_tok) and np.array_equal(ts, want_ts)
+            assert abs(score - em.max(axis=1).sum()) < 1e-9
+    # without the framing the closed form is the plain best path and its timesteps are frame numbers
+    em = np.array([[0., 5, 0], [0, 5, 0], [9, 0, 0], [0, 0, 7], [0, 0, 7]])
+    tok, ts = hostlogic.ctc_bracketed_best_path(em, 5, blank=0, sil=None)
+    assert tok.tolist() == [1, 2] and ts.tolist() == [0, 3]
+    assert np.array_equal(tok, hostlogic.ctc_best_path(em, 5, blank=0))
+    tok, ts = hostlogic.ctc_bracketed_best_path(em, 5, blank=0, sil=1)
+    assert tok.tolist() == [1, 2, 1] and ts.tolist() == [0, 4, 6]          # the emitted 1 at frame 0 merged with the opening silence

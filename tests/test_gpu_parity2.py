@@ -237,6 +237,50 @@ def test_pr_inference_helpers_against_the_oracle():
     assert emb["features_hidden"] is None                              # the reference's extra conv pass has no reader
 
 
+def test_flashlight_framed_decode_option():
+    """Wav2Vec2_PR.decoder = "flashlight" (opt-in; PARITY UNPINNED: torchaudio is absent): the decoded ids of every helper are the best path
+    framed by the decoder's silence token and the durations are positions in the framed T + 2 token row
+    (hostlogic.ctc_bracketed_best_path, checked against the restated beam search in tests/test_cpu_host.py), computed on the device
+    for a batch (no host synchronisation) and identical to the host closed form on the model's own logits; the default is untouched;
+    an unknown decoder name or a vocabulary without '(...)' is refused."""
+    from aptai_amd import hostlogic
+    model, cfg, sd, wav = _pr_setup()
+    model.decoder = "flashlight"
+    with pytest.raises(ValueError):                               # the test vocabulary has no silence token yet
+        model.pred_phn_seq(wav, model.vocab)
+    model.decoder = "best_path"
+    vocab = {('(...)' if v == 5 else k): v for k, v in model.vocab.items()}
+    model.vocab = vocab
+    sil, blank = int(vocab['(...)']), int(vocab['(blank)'])
+    base = model.pred_phn_seq(wav, vocab)
+    x = torch.from_numpy(np.stack([wav, np.roll(wav, 3000)])).cuda()
+    lens = torch.tensor([16000, 16000]).cuda()
+    emb0 = model.get_embeddings(x, lens)
+    try:
+        model.decoder = "flashlight"
+        emb = model.get_embeddings(x, lens)
+        for b in range(2):
+            lg = emb["phoneme_logits"][b].T                              # (T, V)
+            want, _ = hostlogic.ctc_bracketed_best_path(lg, lg.shape[0], blank, sil)
+            assert list(emb["phn_pred_seq_idx"][b]) == list(want)
+            assert want[0] == sil and want[-1] == sil
+            inner = list(emb0["phn_pred_seq_idx"][b])
+            assert list(want) in ([sil] + inner + [sil], inner + [sil], [sil] + inner, inner)      # the framing adds at most the two ends
+        got = model.pred_phn_seq(wav, vocab)
+        lg1 = model.get_ctc_logits(wav)
+        want, ts = hostlogic.ctc_bracketed_best_path(lg1, lg1.shape[0], blank, sil)
+        assert list(got["phn_seq_idx"]) == list(want)
+        dur = model.predict_phonemes_durations(wav, vocab)
+        assert list(dur["phn_seq_idx"]) == list(want) and np.allclose(dur["phn_seq_dur"], ts * (len(wav) / lg1.shape[0] / 16000))
+        assert dur["phn_seq_dur"][0] == 0.0 and ts[-1] <= lg1.shape[0] + 1
+        model.decoder = "viterbi"
+        with pytest.raises(ValueError):
+            model.pred_phn_seq(wav, vocab)
+    finally:
+        model.decoder = "best_path"
+    assert list(model.pred_phn_seq(wav, vocab)["phn_seq_idx"]) == list(base["phn_seq_idx"])
+
+
 def test_get_embeddings_grad_against_the_reference_fixture():
     """Wav2Vec2_PR.get_embeddings_grad (models/w2v2_pr.py:91-122): the seven returned tensors against the reference-generated
     `pr_embgrad_2x1s` fixture (bf16 encoder: 1.5e-2 rel-L2 on hidden states and logits), and the gradients that flow from
