@@ -44,6 +44,9 @@ struct LstmArgs {
     int B, Tp, T, bgroup0, nclusters;
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() waits for EVERY outstanding memory operation of the wave (vmcnt(0)):
+// inside the frame loop that would put the latency of the frame-ahead loads and frame-late stores (below) back on the critical path.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 // Gate nonlinearities on the step's critical path: bare v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the libm expf / tanhf and
 // an IEEE divide (~150 instructions per frame and lane): sigmoid(x) = 1 / (1 + 2^(-x log2 e)), tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e))
@@ -128,13 +131,50 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ex + (long)cluster * LC_EX_GRANULES), 0,
                                                                         (int)LC_EX_BYTES, 0x00020000);
 
-    for (int s = 0; s < maxlen; ++s) {
-        f32x4 acc;
+    // The frame's own traffic beside the exchange - its input projection (4 loads per lane) and its results (h, four gates, c: 6
+    // stores per lane) - shares the vector-memory queue with the polling loads, and that queue returns IN ORDER: issued where they are
+    // needed, a frame's loads and the previous frame's store acknowledgements stand in front of every poll (0.5 us of 3.2 per frame with
+    // warm operands, 0.9 of 3.7 with cold ones: tools/lstm_probe.py with the -DAPTAI_EXP_LSTM builds).  So both are moved to the one
+    // place where nothing waits behind them: right after a poll has SUCCEEDED - the next frame's projection is fetched there, a frame
+    // ahead, and the previous frame's results are written there, a frame late; they have the whole matrix / gate / publish phase plus the
+    // peers' publish latency to complete before the next poll could succeed anyway.
+    // (UNCONDITIONAL loads from a clamped row, masked where the value is used: a load under a condition ends in a select or a branch
+    // merge right behind it, i.e. in a wait for the data where it was issued - on the critical path)
+    auto load_x = [&](int s, f32x4& x) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int b = bg * 16 + 4 * q + r;
-            const int t = dir ? lenr[r] - 1 - s : s;
-            acc[r] = s < lenr[r] ? a.xproj[(((long)b * a.Tp + t) * 2 + dir) * 4 * LH + col] : 0.f;
+            int b = bg * 16 + 4 * q + r;
+            b = b < a.B ? b : a.B - 1;
+            int t = dir ? lenr[r] - 1 - s : s;
+            t = t < 0 ? 0 : (t >= a.T ? a.T - 1 : t);
+#if defined(APTAI_EXP_LSTM) && (APTAI_EXP_LSTM & 1)                   // development (tools/lstm_probe.py): timing without the input loads
+            x[r] = 0.01f * (float)(t & 3);
+#else
+            x[r] = a.xproj[(((long)b * a.Tp + t) * 2 + dir) * 4 * LH + col];
+#endif
+        }
+    };
+    float p_gi = 0.f, p_gf = 0.f, p_gg = 0.f, p_go = 0.f, p_c = 0.f, p_h = 0.f;       // results of the previous frame, not yet stored
+    long p_row = -1;
+    auto flush = [&]() {
+        if (p_row >= 0) {
+            a.hout[p_row * 2 * LH + dir * LH + unit] = p_h;
+            if (a.gates) {
+                float* gp = a.gates + (p_row * 2 + dir) * 4 * LH + unit;
+                gp[0] = p_gi; gp[LH] = p_gf; gp[2 * LH] = p_gg; gp[3 * LH] = p_go;
+                a.cstate[(p_row * 2 + dir) * LH + unit] = p_c;
+            }
+        }
+    };
+    f32x4 x_next;
+    load_x(0, x_next);
+    for (int s = 0; s < maxlen; ++s) {
+        const f32x4 x_cur = x_next;
+        f32x4 acc;
+        if (s == 0) {
+            if (maxlen > 1) load_x(1, x_next);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = 0 < lenr[r] ? x_cur[r] : 0.f;
         }
         if (s > 0) {
             // ---- gather h_{s-1}: word (unit u, batch i) at u*16 + i.  Thread reads the 16-byte pieces L = r*256 + tid, r = 0..3:
@@ -145,15 +185,22 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
             for (unsigned spins = 0;;) {
                 bool ok = true;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    g[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, gbase + (unsigned)r * 4096u, 0, 16);
+                for (int r = 0; r < 4; ++r) g[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, gbase + (unsigned)r * 4096u, 0, 16);
+                __builtin_amdgcn_sched_barrier(0);                     // all four loads in flight before the first tag is looked at
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
                     ok &= ((g[r][0] >> 30) & 1u) == want && ((g[r][1] >> 30) & 1u) == want && ((g[r][2] >> 30) & 1u) == want &&
                           ((g[r][3] >> 30) & 1u) == want;
-                }
                 if (__all(ok)) break;
                 spin_or_fail(spins, a.status);
                 if (spins == 0x80000000u) break;
             }
+#if !(defined(APTAI_EXP_LSTM) && (APTAI_EXP_LSTM & 2))                // development: timing without the per-frame result stores
+            flush();                                                    // frame s-1's results, and
+#endif
+            if (s + 1 < maxlen) load_x(s + 1, x_next);                  // frame s+1's projection: nothing polls behind them for a while
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = s < lenr[r] ? x_cur[r] : 0.f;       // (first touch of the prefetched values: behind the poll)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // element (i, u): MFMA image word = c*256 + (qq*16 + i)*4 + e with qq = u >> 6 = r, c = (u & 63) >> 2 = tid >> 4,
@@ -162,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) hs[base + 4 * e4] = __uint_as_float(g[r][e4] & ~(1u << 30));
             }
-            __syncthreads();
+            lds_barrier();
             // two accumulator chains: a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles, an independent one issues after 32
             f32x4 acc2 = (f32x4)(0.f);
 #pragma unroll
@@ -174,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
                 acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], w[4 * c + 3], acc2, 0, 0, 0);
             }
             acc += acc2;
-            __syncthreads();                                            // the image is free for the next frame's gather
+            lds_barrier();                                            // the image is free for the next frame's gather
         }
         // ---- the four gates of (utterance 4q + slot, unit) sit in the four lanes of the quad, register = slot: 4 x 4 transpose
         const float gi = sigm_fast(quad_pick<0>(acc, gate)), gf = sigm_fast(quad_pick<1>(acc, gate)),
@@ -184,17 +231,14 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
         const bool act = s < mylen;
         if (act) { c_st = c_new; h_st = h_new; }
         __builtin_amdgcn_raw_buffer_store_b32(word30(tau(s), h_st), rsrc, (unsigned)(((s & 1) * 4096 + unit * 16 + myrow) * 4), 0, 16);
+        p_row = -1;
         if (act) {
             const int t = dir ? mylen - 1 - s : s;
-            const long row = (long)myb * a.Tp + t;
-            a.hout[row * 2 * LH + dir * LH + unit] = h_new;
-            if (a.gates) {
-                float* gp = a.gates + (row * 2 + dir) * 4 * LH + unit;
-                gp[0] = gi; gp[LH] = gf; gp[2 * LH] = gg; gp[3 * LH] = go;
-                a.cstate[(row * 2 + dir) * LH + unit] = c_new;
-            }
+            p_row = (long)myb * a.Tp + t;
+            p_gi = gi; p_gf = gf; p_gg = gg; p_go = go; p_c = c_new; p_h = h_new;
         }
     }
+    flush();
     // frames beyond each utterance: zeros (pad_packed_sequence) for this workgroup's 16 units
     for (int i = 0; i < 16; ++i) {
         const int b = bg * 16 + i;
@@ -246,13 +290,22 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
         const int t = dir ? len - 1 - s : s;
         const long row = (long)b * a.Tp + t;
         float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, c = 0.f, cprev = 0.f, dho = 0.f;
+#if defined(APTAI_EXP_LSTM) && (APTAI_EXP_LSTM & 4)                   // development: timing without the saved-state loads
+        if (act) { gi = 0.4f; gf = 0.6f; gg = 0.1f; go = 0.5f; c = 0.2f; cprev = 0.1f; dho = 0.01f * (float)(t & 3); }
+        if (false) {
+#else
         if (act) {
+#endif
             const float* gp = a.gates_in + (row * 2 + dir) * 4 * LH + unit;
             gi = gp[0]; gf = gp[LH]; gg = gp[2 * LH]; go = gp[3 * LH];
             c = a.cstate_in[(row * 2 + dir) * LH + unit];
             if (s > 0) cprev = a.cstate_in[((row + (dir ? 1 : -1)) * 2 + dir) * LH + unit];
             dho = a.dhout[row * 2 * LH + dir * LH + unit];
         }
+        // (The frame-ahead / frame-late treatment of the forward kernel was tried here as well - 7 loads fetched a frame ahead, 4 stores
+        // written a frame late, both right behind a successful poll: 3.04-3.16 us per frame against 3.06-3.09 as written, tools/lstm_probe.py -
+        // no gain: this kernel's 11 per-frame accesses are 16 segments of 16 bytes each per wave, and it is their number, not their latency,
+        // that the next poll waits behind.  Without them the frame takes 2.63 us.)
         const float tc = tanh_fast(c);                                // needs only this frame's loads: off the exchange's critical path
         float dh_rec = 0.f;
         if (n > 0) {
@@ -263,10 +316,13 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
             for (unsigned spins = 0;;) {
                 bool ok = true;
 #pragma unroll
-                for (int src = 0; src < 16; ++src) {
-                    g[src] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, gbase + (unsigned)src * 1024u, 0, 16);
-                    ok &= (g[src] & 1u) == want;
-                }
+                for (int src = 0; src < 16; ++src) g[src] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, gbase + (unsigned)src * 1024u, 0, 16);
+                // all sixteen loads in flight before the first tag is looked at: left to itself the scheduler may pair each compare with
+                // its load and wait in between (seen once while this loop was being restructured: eight L2 round trips one after the
+                // other, 4.7 instead of 3.1 us per frame)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int src = 0; src < 16; ++src) ok &= (g[src] & 1u) == want;
                 if (__all(ok)) break;
                 spin_or_fail(spins, a.status);
                 if (spins == 0x80000000u) break;
@@ -282,14 +338,19 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
             const float d_i = dc * gg, d_g = dc * gi, d_f = dc * cprev;
             pi = d_i * gi * (1.f - gi); pf = d_f * gf * (1.f - gf); pg = d_g * (1.f - gg * gg); po = d_o * go * (1.f - go);
             dc = dc * gf;
-            float* dgp = a.dgates + (row * 2 + dir) * 4 * LH + unit;
-            dgp[0] = pi; dgp[LH] = pf; dgp[2 * LH] = pg; dgp[3 * LH] = po;
+#if defined(APTAI_EXP_LSTM) && (APTAI_EXP_LSTM & 8)                   // development: timing without the per-frame gradient stores
+            if (n + 1 == maxlen)
+#endif
+            {
+                float* dgp = a.dgates + (row * 2 + dir) * 4 * LH + unit;
+                dgp[0] = pi; dgp[LH] = pf; dgp[2 * LH] = pg; dgp[3 * LH] = po;
+            }
         }
         if (n + 1 < maxlen) {
             // ---- A image: element (i = eb, kk = gate*16 + eu): word = c*256 + (gate*16 + eb)*4 + e, c = eu >> 2, e = eu & 3
             const int base = (eu >> 2) * 256 + eb * 4 + (eu & 3);
             dgs[base] = pi; dgs[base + 64] = pf; dgs[base + 128] = pg; dgs[base + 192] = po;
-            __syncthreads();
+            lds_barrier();
             f32x4 acc[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4)(0.f);
@@ -302,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
                     for (int nt = 0; nt < 4; ++nt)
                         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], w[nt][4 * cc + e], acc[nt], 0, 0, 0);
             }
-            __syncthreads();
+            lds_barrier();
             // ---- publish the partial dh_{t-1}: element (utterance 4q + r, unit 64w + 16nt + j) -> dest 4w + nt, unit_l j
             // the lane's four utterances 4q .. 4q+3 of one (dest, unit) are four ADJACENT words: one 16-byte store
             const unsigned t = tau(n);
