@@ -401,8 +401,20 @@ int launch_cluster(bool backward, LstmArgs a, void* workspace, int64_t B, hipStr
             APTAI_FAIL(APTAI_ERR_LAUNCH, "aptai_lstm: hipMemsetAsync of the exchange area failed");
         a.nclusters = n * 2;
         const unsigned grid = 8u * LC_WG * (unsigned)ceil_div(a.nclusters, 8);
-        if (backward) APTAI_LAUNCH(lstm_cluster_bwd_kernel, dim3(grid), dim3(256), 0, stream, a);
-        else APTAI_LAUNCH(lstm_cluster_fwd_kernel, dim3(grid), dim3(256), 0, stream, a);
+        // An LDS request the kernels do not use (APTAI_LSTM_LDS_KB, default 136 of the CU's 160 KB; 0 = none), so that no LDS-staged
+        // kernel of another stream - the GEMM and attention blocks of the frozen encoder in the pipelined Force_APTAI step - shares a
+        // compute unit with these latency chains: beside them a frame took 1.8 x its stand-alone time (their LDS-DMA traffic fills the
+        // CU's vector-memory path in front of the polling loads; wave priority does not reach there).  Measured, interleaved on one box:
+        // Force_APTAI bf16 step 6.73 / 6.75 ms without, 6.36 / 6.37 ms with; exact-index f32x3 12.84 -> 12.64 ms.  Results unchanged.
+        static const int lds_kb = getenv("APTAI_LSTM_LDS_KB") ? atoi(getenv("APTAI_LSTM_LDS_KB")) : 136;
+        const int smem = lds_kb > 0 ? (lds_kb > 140 ? 140 : lds_kb) * 1024 : 0;
+        if (smem > 0) {
+            static const hipError_t e1 = hipFuncSetAttribute((const void*)lstm_cluster_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+            static const hipError_t e2 = hipFuncSetAttribute((const void*)lstm_cluster_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+            APTAI_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, "aptai_lstm: cannot reserve the LDS of APTAI_LSTM_LDS_KB");
+        }
+        if (backward) APTAI_LAUNCH(lstm_cluster_bwd_kernel, dim3(grid), dim3(256), smem, stream, a);
+        else APTAI_LAUNCH(lstm_cluster_fwd_kernel, dim3(grid), dim3(256), smem, stream, a);
         APTAI_CHECK_LAUNCH(backward ? "lstm_cluster_bwd_kernel" : "lstm_cluster_fwd_kernel");
     }
     return APTAI_OK;

@@ -14,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 KNOBS = ("APTAI_GEMM_TILE", "APTAI_GEMM_SPLITN", "APTAI_LN_DEFER", "APTAI_FORCE_ENC_TILE", "APTAI_GEMM_RASTER", "APTAI_EPI_RUNTIME",
-         "APTAI_CONV0_MFMA", "APTAI_CONV0_BWD_MFMA", "APTAI_GEMM_M64", "APTAI_GEMM_F256")
+         "APTAI_CONV0_MFMA", "APTAI_CONV0_BWD_MFMA", "APTAI_GEMM_M64", "APTAI_GEMM_F256", "APTAI_LSTM_LDS_KB")
 
 
 def _child(mode, path, env_extra):
@@ -82,6 +82,6 @@ def test_force_encoder_tile_knob_does_not_change_the_force_step(tmp_path):
     whole-CU workgroups stay out of the BiLSTM's way; 0 = the dispatcher's rule).  Same K walk per element -> the decoded ids, losses and
     trajectories are equal."""
     ref = _child("force", tmp_path / "ref.pt", {})
-    for env in ({"APTAI_FORCE_ENC_TILE": "0"}, {"APTAI_FORCE_ENC_TILE": "64"}):
-        got = _child("force", tmp_path / "got.pt", env)
+    for env in ({"APTAI_FORCE_ENC_TILE": "0"}, {"APTAI_FORCE_ENC_TILE": "64"}, {"APTAI_LSTM_LDS_KB": "0"}):     # (the last: the BiLSTM's
+        got = _child("force", tmp_path / "got.pt", env)                                                         #  unused LDS request, csrc/lstm.hip)
         _compare(ref, got, True, str(env))
