@@ -435,3 +435,38 @@ def test_lstm_timeout_status_raises_on_the_product_path():
             model(0, **b, _phn_pred_list=lists)
         assert ops.lstm_status("cuda:0") == 0                          # cleared by the raise: the next step is judged on its own
         model(0, **b, _phn_pred_list=lists)
+
+
+def test_force_aptai_with_the_flashlight_framed_decode():
+    """Wav2Vec2_PR.decoder = "flashlight" inside Force_APTAI (opt-in, PARITY UNPINNED - INTEGRATION.md "The CTC decoder"): the phoneme sequence
+    the aligner embeds is the best path framed by the silence token, produced on the device (no host synchronisation in the step); the step
+    runs, its alignment targets are ids of the framed sequence, and the default decode is what it was."""
+    from oracle import synth
+    from aptai_amd.config import W2V2Config
+    z, meta = load_golden("force_aptai_1x2s")
+    pr_cfg = W2V2Config.from_any(meta["pr_cfg"])
+    sd = synth.make_state_dict(synth.force_aptai_param_shapes(pr_cfg, meta["vocab_len"]), meta["seed"])
+    sd["w2v2_pr.pr_head.bias"][0] += meta["blank_bias"]
+    model, _ = _build(meta, sd)
+    model.train()
+    batch = {k: v.cuda() for k, v in synth.synth_aptai_batch(pr_cfg, 2, 24000, seed=5, n_phn=40).items()}
+    batch["phoneme_labels"] = torch.zeros(2, 4, dtype=torch.int32).cuda()
+    sil = 1
+    out0 = model(0, **batch)
+    base = [list(map(int, q)) for q in out0["pred_ctc_phn_seq"]]
+    model.w2v2_pr.decoder = "flashlight"
+    try:
+        out = model(0, **batch)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        assert np.isfinite(out["loss"].item())
+        framed = [list(map(int, q)) for q in out["pred_ctc_phn_seq"]]
+        for f, q in zip(framed, base):
+            assert f[0] == sil and f[-1] == sil and f in ([sil] + q + [sil], q + [sil], [sil] + q, q), (f, q)
+            assert len(f) < model.max_phn_seq_len
+        for frames, f in zip(out["pred_frame_phns"], framed):
+            assert set(map(int, frames)) <= set(f)            # every frame is aligned to a phoneme of the framed sequence
+    finally:
+        model.w2v2_pr.decoder = "best_path"
+    again = [list(map(int, q)) for q in model(0, **batch)["pred_ctc_phn_seq"]]
+    assert again == base
