@@ -261,9 +261,9 @@ class Force_APTAI(nn.Module):
             step0 = self.w2v2_pr.wav2vec2._step
             torch.cuda.synchronize(audio_inputs.device)
             # thread-local capture: under data parallelism the process group's watchdog thread polls its events meanwhile
-            # (128-row GEMM tiles in the side-stream pass: whole-CU 256-row workgroups keep the heads' BiLSTM clusters out - ops.auto_tile)
+            # (APTAI_FORCE_ENC_TILE forces one GEMM tile in the side-stream pass - ops.auto_tile; default 0 = the dispatcher's rule, see aptai_amd/graphed.py)
             with torch.cuda.graph(ge.graph, stream=self._enc_stream, capture_error_mode="thread_local"), \
-                    ops.auto_tile(int(os.environ.get("APTAI_FORCE_ENC_TILE", "128"))):
+                    ops.auto_tile(int(os.environ.get("APTAI_FORCE_ENC_TILE", "0"))):
                 ge.out = self._encode(ge.audio, ge.lengths)
             self.w2v2_pr.wav2vec2._step = step0                        # capturing issued nothing
         except Exception as e:                                         # noqa: BLE001 - keep training, eagerly

@@ -689,7 +689,10 @@ class GraphedForceStep:
         pool = torch.cuda.graph_pool_handle()
         # ---- encoder graph (side stream): static inputs -> enc.{ac, ids, nlen, frame_lens}
         self.g_enc = torch.cuda.CUDAGraph()
-        enc_tile = int(os.environ.get("APTAI_FORCE_ENC_TILE", "128"))      # ops.auto_tile: keep whole-CU workgroups out of the side stream
+        enc_tile = int(os.environ.get("APTAI_FORCE_ENC_TILE", "0"))
+        # ^ ops.auto_tile around the side-stream pass.  Rounds 3-4a forced 128-row tiles here: whole-CU workgroups kept the heads' BiLSTM
+        # clusters waiting (12 % of the step).  Since the cluster kernels hold their compute units alone (csrc/lstm.hip, APTAI_LSTM_LDS_KB)
+        # the dispatcher's own rule is the faster one again: 6.36 ms with 128, 6.09 ms with 0, 6.63 ms with 192 (interleaved, one box).
         with torch.cuda.graph(self.g_enc, pool=pool, stream=self._enc_stream, capture_error_mode=_CAPTURE_MODE), ops.auto_tile(enc_tile):
             self.enc = model._encode(self.audio, self.lengths)
         # ---- heads graph: its own copies of the encoder outputs (the next encoder replay overwrites enc.*)

@@ -78,10 +78,10 @@ def test_conv0_knobs_agree_within_summation_order(tmp_path):
 
 
 def test_force_encoder_tile_knob_does_not_change_the_force_step(tmp_path):
-    """APTAI_FORCE_ENC_TILE: which GEMM tile the side-stream encoder graph of GraphedForceStep is captured with (default 128, so that
-    whole-CU workgroups stay out of the BiLSTM's way; 0 = the dispatcher's rule).  Same K walk per element -> the decoded ids, losses and
+    """APTAI_FORCE_ENC_TILE: which GEMM tile the side-stream encoder graph of GraphedForceStep is captured with (default 0 = the
+    dispatcher's rule; 128 was the default while whole-CU workgroups could get in the BiLSTM's way).  Same K walk per element -> the decoded ids, losses and
     trajectories are equal."""
     ref = _child("force", tmp_path / "ref.pt", {})
-    for env in ({"APTAI_FORCE_ENC_TILE": "0"}, {"APTAI_FORCE_ENC_TILE": "64"}, {"APTAI_LSTM_LDS_KB": "0"}):     # (the last: the BiLSTM's
+    for env in ({"APTAI_FORCE_ENC_TILE": "128"}, {"APTAI_FORCE_ENC_TILE": "64"}, {"APTAI_LSTM_LDS_KB": "0"}):     # (the last: the BiLSTM's
         got = _child("force", tmp_path / "got.pt", env)                                                         #  unused LDS request, csrc/lstm.hip)
         _compare(ref, got, True, str(env))
