@@ -1,6 +1,12 @@
 // BiLSTM(256 -> 256, one layer, packed sequences) of the Force_APTAI regression head (models/modules.py:195,204-206), forward
 // and backward through time, as COOPERATING workgroups (gfx950).
 //
+// Gate layout in memory (round 4): the input projections, the saved gates and the pre-activation gradients are [frame][direction][unit][gate]
+// - GATE-INTERLEAVED, column dir * 1024 + unit * 4 + gate (gate = i, f, g, o), not torch's gate-major [gate][unit]: a lane then moves the
+// four gates of its (utterance, unit) as ONE 16-byte access and a wave's input-projection load is 64 contiguous bytes per utterance
+// (gate-major: four 4-byte accesses 1 KB apart per lane, 16-byte segments).  The host permutes the ROWS of W_ih / b_ih + b_hh once per
+// step (aptai_amd/modules.py, ops.lstm_gate_perm), so x W_ih^T arrives in this order and dW_ih / db leave in it; W_hh is read as stored.
+//
 // The recurrence is sequential over T = 499 frames and tiny per frame (16 utterances x 256 x 1024 MACs per direction), so the
 // step latency is everything.  The first build ran one 256-thread block per (utterance, direction) and re-streamed the 1 MB
 // fp32 W_hh from L2 on every frame: 12 us per frame, 6 ms forward + 13.7 ms backward per training step (rocprofv3, round 2).
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
 #if defined(APTAI_EXP_LSTM) && (APTAI_EXP_LSTM & 1)                   // development (tools/lstm_probe.py): timing without the input loads
             x[r] = 0.01f * (float)(t & 3);
 #else
-            x[r] = a.xproj[(((long)b * a.Tp + t) * 2 + dir) * 4 * LH + col];
+            x[r] = a.xproj[(((long)b * a.Tp + t) * 2 + dir) * 4 * LH + unit * 4 + gate];     // 16 lanes = 64 contiguous bytes
 #endif
         }
     };
@@ -160,8 +166,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_fwd_kernel(LstmArgs a) {
         if (p_row >= 0) {
             a.hout[p_row * 2 * LH + dir * LH + unit] = p_h;
             if (a.gates) {
-                float* gp = a.gates + (p_row * 2 + dir) * 4 * LH + unit;
-                gp[0] = p_gi; gp[LH] = p_gf; gp[2 * LH] = p_gg; gp[3 * LH] = p_go;
+                *(f32x4*)(a.gates + (p_row * 2 + dir) * 4 * LH + unit * 4) = (f32x4){p_gi, p_gf, p_gg, p_go};
                 a.cstate[(p_row * 2 + dir) * LH + unit] = p_c;
             }
         }
@@ -296,8 +301,8 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
 #else
         if (act) {
 #endif
-            const float* gp = a.gates_in + (row * 2 + dir) * 4 * LH + unit;
-            gi = gp[0]; gf = gp[LH]; gg = gp[2 * LH]; go = gp[3 * LH];
+            const f32x4 g4 = *(const f32x4*)(a.gates_in + (row * 2 + dir) * 4 * LH + unit * 4);
+            gi = g4[0]; gf = g4[1]; gg = g4[2]; go = g4[3];
             c = a.cstate_in[(row * 2 + dir) * LH + unit];
             if (s > 0) cprev = a.cstate_in[((row + (dir ? 1 : -1)) * 2 + dir) * LH + unit];
             dho = a.dhout[row * 2 * LH + dir * LH + unit];
@@ -342,8 +347,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
             if (n + 1 == maxlen)
 #endif
             {
-                float* dgp = a.dgates + (row * 2 + dir) * 4 * LH + unit;
-                dgp[0] = pi; dgp[LH] = pf; dgp[2 * LH] = pg; dgp[3 * LH] = po;
+                *(f32x4*)(a.dgates + (row * 2 + dir) * 4 * LH + unit * 4) = (f32x4){pi, pf, pg, po};
             }
         }
         if (n + 1 < maxlen) {
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void lstm_cluster_bwd_kernel(LstmArgs a) {
         int l = a.lens[bb];
         l = l < a.T ? l : a.T;
         for (int t = l + (tid >> 6); t < a.Tp; t += 4) {
-            float* dgp = a.dgates + (((long)bb * a.Tp + t) * 2 + dir) * 4 * LH + (lane >> 4) * LH + k * 16 + (lane & 15);
+            float* dgp = a.dgates + (((long)bb * a.Tp + t) * 2 + dir) * 4 * LH + k * 64 + lane;       // units 16k .. 16k+15, four gates each
             *dgp = 0.f;
         }
     }
@@ -430,7 +434,8 @@ extern "C" int aptai_lstm_fwd(const float* xproj, const float* whh, const int32_
     APTAI_REQUIRE(hidden == LH, "aptai_lstm_fwd: built for hidden size 256");
     APTAI_REQUIRE((gates == nullptr) == (cstate == nullptr), "aptai_lstm_fwd: gates and cstate go together");
     APTAI_REQUIRE(B > 0 && T > 0 && Tp >= T, "aptai_lstm_fwd: bad sizes");
-    APTAI_REQUIRE((uintptr_t)whh % 16 == 0 && (uintptr_t)workspace % 16 == 0, "aptai_lstm_fwd: whh / workspace must be 16-byte aligned");
+    APTAI_REQUIRE((uintptr_t)whh % 16 == 0 && (uintptr_t)workspace % 16 == 0 && (uintptr_t)gates % 16 == 0,
+                  "aptai_lstm_fwd: whh / workspace / gates must be 16-byte aligned");
     LstmArgs a;
     memset(&a, 0, sizeof(a));
     a.xproj = xproj; a.whh = whh; a.lens = lens; a.hout = hout; a.gates = gates; a.cstate = cstate;
@@ -443,6 +448,7 @@ extern "C" int aptai_lstm_bwd(const float* dhout, const float* whh, const int32_
     APTAI_REQUIRE(dhout && whh && lens && gates && cstate && dgates && workspace, "aptai_lstm_bwd: null pointer");
     APTAI_REQUIRE(hidden == LH, "aptai_lstm_bwd: built for hidden size 256");
     APTAI_REQUIRE(B > 0 && T > 0 && Tp >= T, "aptai_lstm_bwd: bad sizes");
+    APTAI_REQUIRE((uintptr_t)gates % 16 == 0 && (uintptr_t)dgates % 16 == 0, "aptai_lstm_bwd: gates / dgates must be 16-byte aligned");
     LstmArgs a;
     memset(&a, 0, sizeof(a));
     a.dhout = dhout; a.whh = whh; a.lens = lens; a.gates_in = gates; a.cstate_in = cstate; a.dgates = dgates;

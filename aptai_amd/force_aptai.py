@@ -52,8 +52,10 @@ def force_heads_fwd(ac, st, P):
     ops.sgemm(s.att, _NPHN, 1, s.k, 128, 1, Tp, 128, _NPHN, out=s.cat, ldc=256, batch=B, bsa=Tp * _NPHN, bsb=_NPHN * 128,
               bsc=Tp * 256)
     s.att_out, s.lm, s.lr = ops.layernorm_f32_fwd(s.cat, ln_w, ln_b)
-    s.wih = torch.cat([wih0, wih1]).contiguous()                                                          # [2048][256]
-    bsum = torch.cat([bih0 + bhh0, bih1 + bhh1]).contiguous()
+    # rows in the LSTM kernels' gate-interleaved order (csrc/lstm.hip: column dir * 1024 + unit * 4 + gate of xproj / gates / dgates)
+    perm = ops.lstm_gate_perm(dev)[0]
+    s.wih = torch.cat([wih0, wih1])[perm].contiguous()                                                    # [2048][256]
+    bsum = torch.cat([bih0 + bhh0, bih1 + bhh1])[perm].contiguous()
     xproj = ops.linear_f32(s.att_out, s.wih, bsum)                                                         # [M][2048]
     s.whh = torch.stack([whh0, whh1]).contiguous()                                                         # [2][1024][256]
     s.hout, s.gates, s.cst = ops.lstm_fwd(xproj, s.whh, st.rnn_lens, B, Tp, T)
@@ -107,6 +109,10 @@ def force_heads_bwd(s, st, P, ac, gloss=None):
     dwhh0 = ops.sgemm(dgates[1:], 1, 2048, s.hout, 512, 1, 1024, 256, M - 1)
     dwhh1 = ops.sgemm(dgates[:, 1024:], 1, 2048, s.hout[1:, 256:], 512, 1, 1024, 256, M - 1)
     datt_out = ops.sgemm(dgates, 2048, 1, s.wih, 256, 1, M, 256, 2048)
+    # the four products above have the gate axis in the kernels' interleaved order: back to torch's gate-major rows
+    inv = ops.lstm_gate_perm(dev)[1]
+    dwih, dbg = dwih[inv], dbg[inv]
+    dwhh0, dwhh1 = dwhh0[inv[:1024]], dwhh1[inv[:1024]]
     dcat, dln_w, dln_b = ops.layernorm_f32_bwd(datt_out, s.cat, s.lm, s.lr, ln_w)
     # ---- cross attention
     d_att = ops.sgemm(dcat, 256, 1, s.k, 1, 128, Tp, _NPHN, 128, batch=B, bsa=Tp * 256, bsb=_NPHN * 128, bsc=Tp * _NPHN)

@@ -171,7 +171,10 @@ class _LstmCoreFn(torch.autograd.Function):
         # dW_hh[dir] = sum_t dgates[t][dir]^T h_prev[t][dir]: the zero rows between utterances make one shifted product exact
         dwhh0 = ops.sgemm(dgates[1:], 1, 2048, hout, 512, 1, 1024, 256, M - 1)
         dwhh1 = ops.sgemm(dgates[:, 1024:], 1, 2048, hout[1:, 256:], 512, 1, 1024, 256, M - 1)
-        return dgates, dwhh0, dwhh1, None, None, None, None
+        # dgates is in the kernels' gate-interleaved column order, like xproj (the caller permuted W_ih's rows): the rows of the two
+        # products come out in that order and go back to weight_hh's gate-major one
+        inv = ops.lstm_gate_perm(dgates.device)[1][:1024]
+        return dgates, dwhh0[inv], dwhh1[inv], None, None, None, None
 
 
 class _TanhDropFn(torch.autograd.Function):
@@ -211,8 +214,10 @@ class RNN(nn.Module):
         xp = torch.zeros((B, Tp, D), device=dev, dtype=torch.float32)
         xp[:, :T] = embeddings
         l = self.lstm
-        wih = torch.cat([l.weight_ih_l0, l.weight_ih_l0_reverse])
-        bsum = torch.cat([l.bias_ih_l0 + l.bias_hh_l0, l.bias_ih_l0_reverse + l.bias_hh_l0_reverse])
+        # rows in the LSTM kernels' gate-interleaved order (csrc/lstm.hip; autograd takes the gradients back through the gather)
+        perm = ops.lstm_gate_perm(dev)[0]
+        wih = torch.cat([l.weight_ih_l0, l.weight_ih_l0_reverse])[perm]
+        bsum = torch.cat([l.bias_ih_l0 + l.bias_hh_l0, l.bias_ih_l0_reverse + l.bias_hh_l0_reverse])[perm]
         xproj = _LinearFn.apply(xp.view(B * Tp, D), wih, bsum)
         lens_i32 = torch.tensor(run_lens, dtype=torch.int32, device=dev)
         hout = _LstmCoreFn.apply(xproj, l.weight_hh_l0, l.weight_hh_l0_reverse, lens_i32, B, Tp, T)

@@ -916,8 +916,27 @@ def lstm_status(device) -> int:
     return 0 if w is None else int(w.abs().max().item())
 
 
+_GATE_PERM = {}
+
+
+def lstm_gate_perm(device):
+    """(perm, inv) int64 [2048]: the gate-INTERLEAVED column order of aptai_lstm_fwd / _bwd (xproj, gates, dgates: column
+    dir * 1024 + unit * 4 + gate) against torch's gate-major order (dir * 1024 + gate * 256 + unit).  `w[perm]` puts the rows of
+    cat(weight_ih_l0, weight_ih_l0_reverse) (or a gate-major vector) into the kernels' order; `t[..., inv]` (or `g[inv]` on rows) brings a
+    tensor in the kernels' order back to torch's."""
+    key = str(device)
+    if key not in _GATE_PERM:
+        d, u, g = torch.meshgrid(torch.arange(2), torch.arange(256), torch.arange(4), indexing="ij")
+        perm = (d * 1024 + g * 256 + u).reshape(-1)                  # position dir*1024 + unit*4 + gate <- gate-major index
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(2048)
+        _GATE_PERM[key] = (perm.to(device), inv.to(device))
+    return _GATE_PERM[key]
+
+
 def lstm_fwd(xproj, whh, lens_i32, B, Tp, T, save=True):
-    """whh [2][1024][256] (weight_hh_l0 | weight_hh_l0_reverse).  Returns (hout [B*Tp][512], gates, cstate)."""
+    """xproj in the gate-interleaved column order (lstm_gate_perm); whh [2][1024][256] (weight_hh_l0 | weight_hh_l0_reverse, as stored).
+    Returns (hout [B*Tp][512], gates, cstate); gates in the interleaved order."""
     _dev(xproj, whh, lens_i32)
     dev = xproj.device
     hout = torch.empty((B * Tp, 512), device=dev, dtype=torch.float32)

@@ -400,7 +400,9 @@ int64_t aptai_layernorm_f32_bwd_workspace_bytes(int64_t cols);
 /* nn.LSTM(256,256,bidirectional) over packed sequences (modules.py:195,204-206): xproj [B*Tp][2][1024] = x W_ih^T + b_ih + b_hh,
  * whh [2][1024][256] (weight_hh_l0, weight_hh_l0_reverse as stored), lens int32 [B]; hout [B*Tp][512] (zeros beyond lens);
  * gates (post-activation i,f,g,o) [B*Tp][2][1024] and cstate [B*Tp][2][256] are saved for the backward (both null in
- * inference).  16 cooperating workgroups per (16 utterances, direction) keep W_hh in registers and exchange h through
+ * inference).  GATE LAYOUT of xproj, gates and dgates (round 4): column dir * 1024 + unit * 4 + gate - gate-INTERLEAVED, i.e. the rows of
+ * W_ih and of the bias sum permuted from torch's gate-major order by the caller (row unit * 4 + gate of the operand = row gate * 256 + unit
+ * of weight_ih_l0); whh keeps torch's order.  The *_serial cross-check kernels keep the gate-major layout.  16 cooperating workgroups per (16 utterances, direction) keep W_hh in registers and exchange h through
  * `workspace` (aptai_lstm_workspace_bytes; zero-initialised ONCE by the caller, its first 256 bytes are a status word that
  * turns non-zero if a bounded wait ever timed out).  bwd: dgates [B*Tp][2][1024] = gradients w.r.t. the gate pre-activations
  * (zeros beyond lens). */

@@ -89,7 +89,12 @@ def test_lstm_kernels_match_torch_packed_lstm(B, lens):
     xp[:, :T] = x.detach()
     wih = torch.cat([lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]).detach()
     bsum = torch.cat([lstm.bias_ih_l0 + lstm.bias_hh_l0, lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse]).detach()
-    xproj = ops.linear_f32(xp.view(B * Tp, 256).cuda(), wih.cuda(), bsum.cuda())
+    # the cluster kernels take / return the gate axis interleaved (column dir * 1024 + unit * 4 + gate): W_ih's rows permuted going in,
+    # everything with a gate axis permuted back coming out; the serial cross-check kernels keep torch's gate-major order
+    perm, inv = ops.lstm_gate_perm("cuda")
+    xproj_gm = ops.linear_f32(xp.view(B * Tp, 256).cuda(), wih.cuda(), bsum.cuda())
+    xproj = ops.linear_f32(xp.view(B * Tp, 256).cuda(), wih.cuda()[perm].contiguous(), bsum.cuda()[perm].contiguous())
+    assert torch.equal(xproj[:, inv], xproj_gm)
     whh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]).detach().contiguous()
     lens_t = torch.tensor(lens, dtype=torch.int32).cuda()
     hout, gates, cst = ops.lstm_fwd(xproj, whh.cuda(), lens_t, B, Tp, T)
@@ -100,14 +105,17 @@ def test_lstm_kernels_match_torch_packed_lstm(B, lens):
     for b, L in enumerate(lens):
         assert hout.view(B, Tp, 512)[b, L:].abs().max().item() == 0.0
     # the serial kernels see the same inputs: same recurrence, different summation order
-    h2, g2, c2 = ops.lstm_fwd_serial(xproj, whh.transpose(1, 2).contiguous().cuda(), lens_t, B, Tp, T)
+    h2, g2, c2 = ops.lstm_fwd_serial(xproj_gm, whh.transpose(1, 2).contiguous().cuda(), lens_t, B, Tp, T)
     assert (h2 - hout).abs().max().item() < 1e-5
+    for b, L in enumerate(lens):                                   # saved gates: the same numbers, permuted
+        assert (gates.view(B, Tp, 2048)[b, :L][:, inv] - g2.view(B, Tp, 2048)[b, :L]).abs().max().item() < 1e-5
     dh = torch.zeros(B, Tp, 512)
     dh[:, :T] = gout
     dgates = ops.lstm_bwd(dh.view(B * Tp, 512).cuda(), whh.cuda(), lens_t, gates, cst, B, Tp, T)
     torch.cuda.synchronize()
     assert ops.lstm_status("cuda:0") == 0
     dg2 = ops.lstm_bwd_serial(dh.view(B * Tp, 512).cuda(), whh.cuda(), lens_t, g2, c2, B, Tp, T)
+    dgates = dgates[:, inv].contiguous()                           # gate-major from here on, like torch's gradients
     assert (dg2 - dgates).abs().max().item() < 2e-5 * max(1.0, dg2.abs().max().item())
     dx = ops.sgemm(dgates, 2048, 1, wih.cuda(), 256, 1, B * Tp, 256, 2048).view(B, Tp, 256)[:, :T].cpu()
     assert (dx - x.grad).abs().max().item() < 5e-5 * max(1.0, x.grad.abs().max().item())
